@@ -1,0 +1,152 @@
+/*
+ * femasm.h -- C ABI of the MI355X (gfx950) finite-element global-assembly engine.
+ *
+ * Drop-in boundary for the assembly hot path of the CuiCu-618/petsc drivers.  The
+ * reference has no FFI/plugin interface of its own: the hot path is a set of static
+ * functions called from main()/solve_elasticity_*().  Each entry point below names
+ * the reference call site(s) it replaces (P3 = FEM_poisson3D/FEM.cpp,
+ * E2 = FEM_elsatic2D/FEM.cpp, S3 = SGFEM/SGFEM_elastic3D.cpp,
+ * R3 = SGFEM_real/SGFEM_elastic3D.cpp).  INTEGRATION.md shows the driver patch.
+ *
+ * Plain C: no C++ types, no exceptions, no PETSc or torch headers.  All buffers are
+ * caller-owned; every data pointer may be a HOST pointer or a DEVICE (HIP) pointer,
+ * detected with hipPointerGetAttributes.  Host buffers are staged over PCIe.
+ * Return value: 0 = success, otherwise a FEMASM_ERR_* class; text from
+ * femasm_last_error() (thread-local), PETSc style (wrap with CHKERRQ).
+ */
+#ifndef FEMASM_H
+#define FEMASM_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  FEMASM_POISSON3D_Q1      = 0, /* P3: 8-node hex, dof 1, 8 Gauss points                */
+  FEMASM_PLANE_STRAIN2D_Q1 = 1, /* E2: 4-node quad, dof 2, 4 Gauss points               */
+  FEMASM_ELASTIC3D_Q1      = 2  /* S3/R3 (all enrich_type == 0): 8-node hex, dof 3      */
+};
+
+enum {
+  FEMASM_OK = 0,
+  FEMASM_ERR_ARG = 1,      /* bad argument / unsupported combination            */
+  FEMASM_ERR_HIP = 2,      /* a HIP runtime call or kernel launch failed        */
+  FEMASM_ERR_GEOMETRY = 3, /* non-positive or non-finite det(J) at a Gauss point */
+  FEMASM_ERR_NOMEM = 4
+};
+
+/* "mesh": the DMDA the drivers create (P3:658-663, E2:567-578, S3:1185-1198):
+ * BOX stencil, width 1, non-periodic, natural node order n = i + M*(j + N*k). */
+typedef struct {
+  int32_t problem;      /* FEMASM_* problem kind                                              */
+  int32_t reserved;
+  int64_t M, N, P;      /* global node counts per direction (P = 1 in 2-D)                    */
+  int64_t ks, ke;       /* owned node layers [ks,ke) of the slowest direction (z in 3-D, y in
+                           2-D): DMDA slab split.  0,P (0,N in 2-D) on one GPU.               */
+  int64_t cks, cke;     /* node layers [cks,cke) held in coords[] (the DMDA ghosted local
+                           coordinate vector: ks-1 .. ke clipped to the mesh); 0,P on one GPU.
+                           Must cover [max(ks-1,0), ke).                                      */
+  const double *coords; /* node coordinates, interleaved (x,y[,z]), layers [cks,cke)          */
+} femasm_mesh;
+
+/* "material": per-element GaussPointCoefficients array (A14), zero-copy from
+ * VecGetArray(properties) (E2:29-35, S3:51-64, R3:52-68), or uniform constants. */
+enum { FEMASM_MAT_AOS = 0, FEMASM_MAT_UNIFORM = 1 };
+typedef struct {
+  int32_t layout;       /* FEMASM_MAT_AOS | FEMASM_MAT_UNIFORM (K only needs E,nu)            */
+  int32_t stride;       /* doubles per element: 24 (E2) | 400 (S3) | 408/416 (R3)             */
+  int64_t e_ks;         /* first element layer held in gp[] (owned elements start here)       */
+  const double *gp;     /* element index ei + mx*(ej + my*(ek - e_ks))                        */
+  double E, nu;         /* FEMASM_MAT_UNIFORM                                                 */
+} femasm_material;
+
+/* "quad": rule 0 = the reference's 2-point Gauss rule with the literal abscissa
+ * 0.57735026919 and unit weights (P3:152-174, E2:124-135, S3:229-289). */
+typedef struct { int32_t ngp; int32_t rule; } femasm_quad;
+
+/* Dirichlet boundary conditions (A10, A11).  Rows only, diagonal 1.0, no column
+ * elimination, no RHS lifting -- exactly MatZeroRows(A,n,ids,1.0,0,0) /
+ * the _ZERO_ROW_i macro.  The zeroed rows keep their slots in the DMDA pattern
+ * (explicit zeros); femasm_compress_bc_rows() gives PETSc's truncated form. */
+enum {
+  FEMASM_BC_NONE = 0,
+  FEMASM_BC_POISSON_INLOOP = 1,  /* P3:286-290, 328-338, 624-630                       */
+  FEMASM_BC_E2_COMPRESSION = 2,  /* E2:877-887: i=M-1: ux=-1,uy=0 ; i=0: ux=+1,uy=0    */
+  FEMASM_BC_S3_ALLFACES_EXACT = 3 /* S3:1912-1941: 6 faces x 3 dofs, exact displacement */
+};
+typedef struct { int32_t kind; int32_t reserved; } femasm_bc;
+
+typedef struct {
+  double  ms_total;        /* whole call, host wall clock incl. staging               */
+  double  ms_kernel_K;     /* stiffness kernel(s), HIP events on the plan's stream    */
+  double  ms_kernel_rhs;   /* RHS kernels                                             */
+  double  ms_staging;      /* host<->device copies (0 for device buffers)             */
+  double  bytes_K;         /* algorithmic bytes of K assembly           */
+  double  bytes_system;    /* algorithmic bytes of the full system                    */
+  int64_t nel, nrows, nnz; /* local (slab) sizes                                      */
+  int64_t bad_detJ;        /* Gauss points with det(J) <= 0 or NaN                    */
+} femasm_stats;
+
+typedef struct femasm_plan femasm_plan;
+
+/* Build the device-resident plan: slab geometry, DMDA sparsity pattern (bit-exact to
+ * DMCreateMatrix, replaces nothing in the driver -- it is compared against P3:667,
+ * E2:681, S3:1373), reference-element tables.  `device` is the HIP device ordinal. */
+int femasm_plan_create(const femasm_mesh *mesh, const femasm_quad *quad, int device, femasm_plan **out);
+int femasm_plan_destroy(femasm_plan *plan);
+
+/* Launch everything on `stream` (a hipStream_t) instead of the plan's own stream. */
+int femasm_plan_set_stream(femasm_plan *plan, void *stream);
+
+/* Sparsity pattern of the owned rows (A12): rowptr is local (starts at 0, int64 so
+ * 256^3 elastic fits), colidx holds GLOBAL column ids (= PETSc natural numbering for
+ * z-slab layouts).  Device pointers, borrowed until destroy. */
+int femasm_pattern(femasm_plan *plan, int64_t *nrows, int64_t *nnz, const int64_t **rowptr, const int32_t **colidx);
+/* Same, copied into caller-owned HOST arrays (rowptr[nrows+1], colidx[nnz]). */
+int femasm_pattern_copy(femasm_plan *plan, int64_t *rowptr, int32_t *colidx);
+
+/* Explicit element->nonzero scatter map (A13): for each owned element e (k->j->i
+ * order) and local (row r, col c) of its (nen*dof)^2 matrix, the position in the
+ * local csr_values array, or -1 if the row belongs to another slab.  The assembly
+ * kernels use the closed form of this map; this entry materialises it for checks
+ * and for unstructured front-ends.  map_out: HOST or DEVICE, nel*(nen*dof)^2 int64. */
+int femasm_scatter_map(femasm_plan *plan, int64_t *map_out);
+
+/* THE hot path.  Replaces
+ *   P3:675 AssembleA_Poisson + P3:678 AssembleF_Poisson              (bc = POISSON_INLOOP)
+ *   E2:692 AssembleA_Elasticity + E2:694 AssembleF_Elasticity + E2:700 DMDABCApplyCompression
+ *   S3:1384 + S3:1386 + S3:1392  (R3:1402, 1404, 1410)
+ * csr_values[nnz] and b[nrows] receive the owned rows (overwritten, not added to; the
+ * drivers zero A and F first, P3:672-673).  Either may be NULL to skip that half.
+ * On a slab with ks > 0 the partial sums this rank owes to the rank below are left in
+ * the plan's send buffer (femasm_interface_buffers). */
+int femasm_assemble_system(femasm_plan *plan, const femasm_material *material, const femasm_bc *bc,
+                           double *csr_values, double *b, femasm_stats *stats);
+
+/* Multi-GPU slab interface: what MatAssemblyEnd's stash exchange and
+ * DMLocalToGlobal(ADD_VALUES) move in the reference (P3:345-346, 638-639; S3:710-711,
+ * 794-795).  send_*: partial rows of node layer ks-1 (CSR layout of those rows, then the
+ * b slice), owed to rank-1.  recv_*: same shape for node layer ke-1, filled by the caller
+ * from rank+1 (RCCL/MPI).  Counts are in doubles; 0 where there is no neighbour. */
+int femasm_interface_buffers(femasm_plan *plan, double **send_buf, int64_t *send_count,
+                             double **recv_buf, int64_t *recv_count);
+/* own + received, fixed order (deterministic); Dirichlet rows are left untouched. */
+int femasm_interface_apply(femasm_plan *plan, const femasm_bc *bc, double *csr_values, double *b);
+
+/* PETSc's default MatZeroRows storage (keepnonzeropattern off): zeroed rows keep only
+ * their diagonal and the CSR arrays are recompressed.  Outputs HOST or DEVICE,
+ * sized like the inputs; *nnz_out receives the new count. */
+int femasm_compress_bc_rows(femasm_plan *plan, const femasm_bc *bc, const double *csr_values,
+                            int64_t *rowptr_out, int32_t *colidx_out, double *values_out, int64_t *nnz_out);
+
+/* Block until everything queued on the plan's stream has finished. */
+int femasm_plan_sync(femasm_plan *plan);
+
+const char *femasm_last_error(void);
+const char *femasm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

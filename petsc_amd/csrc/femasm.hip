@@ -1,0 +1,568 @@
+// femasm.hip -- C ABI (include/femasm.h) over the gfx950 assembly kernels.
+//
+// One plan = one slab of the structured mesh on one GPU.  The plan owns the pattern
+// arrays, the RHS scratch, the interface send/recv buffers and a stream; the caller owns
+// coordinates, material and outputs (host or device).  No CPU fallback exists: every
+// entry point needs a HIP device and fails loudly without one.
+#include "../../include/femasm.h"
+#include "femasm_kernels.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace femasm;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(call)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (call);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      return fail(FEMASM_ERR_HIP, "%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+  } while (0)
+
+bool is_device_ptr(const void *p) {
+  if (!p) return false;
+  hipPointerAttribute_t at;
+  hipError_t e = hipPointerGetAttributes(&at, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();  // plain host memory: clear the sticky error
+    return false;
+  }
+  return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
+}
+
+inline unsigned nblk(int64_t n, int per = 256) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+struct femasm_plan {
+  int device = 0;
+  int kind = 0;
+  Slab s{};
+  int64_t cke = 0;
+  const double *coords_user = nullptr;  // as given (host or device)
+  double *coords_dev = nullptr;         // device copy if coords_user is host memory
+  const double *coords = nullptr;       // device pointer used by kernels
+  int64_t ncoord = 0;
+
+  int64_t nnodes = 0, nrows = 0, nnz = 0, nel = 0;
+  int64_t *rowptr = nullptr;
+  int32_t *colidx = nullptr;
+
+  // RHS scratch: per-element Fe (Ge)
+  double *elemF = nullptr;
+  // interface buffers (K rows of one node layer in CSR layout, then the b slice)
+  double *send = nullptr, *recv = nullptr;
+  int64_t send_count = 0, recv_count = 0, send_nnz = 0, recv_nnz = 0;
+
+  unsigned long long *bad = nullptr;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+
+  // staging for host-side callers
+  double *stage_vals = nullptr, *stage_b = nullptr, *stage_gp = nullptr;
+  int64_t stage_gp_count = 0;
+};
+
+namespace {
+
+int traits_of(int kind, int &nsd, int &dof, int &nen, int &ngp, int &nfe) {
+  switch (kind) {
+    case KIND_POISSON: nsd = 3; dof = 1; nen = 8; ngp = 8; nfe = 8; return 0;
+    case KIND_PLANE:   nsd = 2; dof = 2; nen = 4; ngp = 4; nfe = 8; return 0;
+    case KIND_ELASTIC: nsd = 3; dof = 3; nen = 8; ngp = 8; nfe = 48; return 0;
+  }
+  return 1;
+}
+
+// number of stored entries of the rows of node layers [l0, l1) of the slowest direction
+int64_t layer_nnz(const Slab &s, int64_t l0, int64_t l1) {
+  const int64_t a = (s.nsd == 3) ? pairs_before(s, 0, 0, l0) : pairs_before(s, 0, l0, 0);
+  const int64_t b = (s.nsd == 3) ? pairs_before(s, 0, 0, l1) : pairs_before(s, 0, l1, 0);
+  return (int64_t)s.dof * s.dof * (b - a);
+}
+
+template <int KIND>
+int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, int64_t s0, int64_t s1, int iface) {
+  using T = Traits<KIND>;
+  if (s1 <= s0) return 0;
+  KArgs a{};
+  a.coords = p->coords;
+  a.gp = (mat && mat->layout == FEMASM_MAT_AOS) ? (p->stage_gp ? p->stage_gp : mat->gp) : nullptr;
+  a.out = out;
+  a.bad = p->bad;
+  a.base_off = (T::NSD == 3) ? row_start(p->s, 0, 0, s0, 0) : row_start(p->s, 0, s0, 0, 0);
+  a.cke = p->cke;
+  a.s0 = s0;
+  a.s1 = s1;
+  a.E = mat ? mat->E : 0.0;
+  a.nu = mat ? mat->nu : 0.0;
+  a.mat_layout = mat ? mat->layout : FEMASM_MAT_UNIFORM;
+  a.mat_stride = mat ? mat->stride : 0;
+  a.bc = bc;
+  a.iface = iface;
+  const int64_t M = p->s.dim[0], N = p->s.dim[1];
+  const int64_t nbx = (M + T::BX - 1) / T::BX;
+  int64_t nb;
+  if (T::NSD == 3) nb = nbx * ((N + T::BY - 1) / T::BY) * ((s1 - s0 + T::BZ - 1) / T::BZ);
+  else             nb = nbx * ((s1 - s0 + T::BY - 1) / T::BY);
+  if (nb > 0x7fffffffLL) return fail(FEMASM_ERR_ARG, "mesh too large for one launch (%lld bricks)", (long long)nb);
+  hipLaunchKernelGGL(k_assemble_rows<KIND>, dim3((unsigned)nb), dim3(256), 0, p->stream, p->s, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+template <int KIND>
+int launch_rhs(femasm_plan *p, const femasm_material *mat, int bc, double *out, int64_t s0, int64_t s1, int iface,
+               bool do_elem) {
+  using T = Traits<KIND>;
+  if (s1 <= s0) return 0;
+  RArgs a{};
+  a.coords = p->coords;
+  a.gp = (mat && mat->layout == FEMASM_MAT_AOS) ? (p->stage_gp ? p->stage_gp : mat->gp) : nullptr;
+  a.elemF = p->elemF;
+  a.out = out;
+  a.cke = p->cke;
+  a.s0 = s0;
+  a.s1 = s1;
+  a.nel = p->nel;
+  a.mat_layout = mat ? mat->layout : FEMASM_MAT_UNIFORM;
+  a.mat_stride = mat ? mat->stride : 0;
+  a.bc = bc;
+  a.iface = iface;
+  if (do_elem && p->nel > 0) {
+    hipLaunchKernelGGL(k_rhs_elem<KIND>, dim3(nblk(p->nel)), dim3(256), 0, p->stream, p->s, a);
+    HIPCHK(hipGetLastError());
+  }
+  const int64_t nn = (T::NSD == 3) ? p->s.dim[0] * p->s.dim[1] * (s1 - s0) : p->s.dim[0] * (s1 - s0);
+  hipLaunchKernelGGL(k_rhs_gather<KIND>, dim3(nblk(nn)), dim3(256), 0, p->stream, p->s, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *femasm_last_error(void) { return g_err.c_str(); }
+const char *femasm_version(void) { return "femasm 0.1 (gfx950)"; }
+
+int femasm_plan_create(const femasm_mesh *mesh, const femasm_quad *quad, int device, femasm_plan **out) {
+  if (!mesh || !out) return fail(FEMASM_ERR_ARG, "femasm_plan_create: null argument");
+  *out = nullptr;
+  int nsd, dof, nen, ngp, nfe;
+  if (traits_of(mesh->problem, nsd, dof, nen, ngp, nfe))
+    return fail(FEMASM_ERR_ARG, "unknown problem kind %d", mesh->problem);
+  if (quad && (quad->rule != 0 || (quad->ngp != 0 && quad->ngp != ngp)))
+    return fail(FEMASM_ERR_ARG, "only the reference 2-point Gauss rule (rule 0, ngp %d) is supported", ngp);
+  const int64_t M = mesh->M, N = mesh->N, P = (nsd == 3) ? mesh->P : 1;
+  const int64_t SL = (nsd == 3) ? P : N;  // extent of the slab direction
+  if (M < 2 || N < 2 || (nsd == 3 && P < 2)) return fail(FEMASM_ERR_ARG, "need at least 2 nodes per direction");
+  if (mesh->ks < 0 || mesh->ke > SL || mesh->ks >= mesh->ke)
+    return fail(FEMASM_ERR_ARG, "bad owned layer range [%lld,%lld) of %lld", (long long)mesh->ks, (long long)mesh->ke,
+                (long long)SL);
+  const int64_t need_lo = mesh->ks > 0 ? mesh->ks - 1 : 0;
+  if (mesh->cks > need_lo || mesh->cke < mesh->ke || mesh->cke > SL || mesh->cks < 0)
+    return fail(FEMASM_ERR_ARG, "coords layers [%lld,%lld) must cover [%lld,%lld)", (long long)mesh->cks,
+                (long long)mesh->cke, (long long)need_lo, (long long)mesh->ke);
+  if (!mesh->coords) return fail(FEMASM_ERR_ARG, "coords is null");
+  if ((double)dof * M * N * P > 2.0e9) return fail(FEMASM_ERR_ARG, "global row count exceeds int32 column ids");
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(FEMASM_ERR_HIP, "no HIP device: the femasm engine has no CPU path");
+  if (device < 0 || device >= ndev) return fail(FEMASM_ERR_ARG, "device %d out of range (%d devices)", device, ndev);
+  HIPCHK(hipSetDevice(device));
+
+  femasm_plan *p = new (std::nothrow) femasm_plan();
+  if (!p) return fail(FEMASM_ERR_NOMEM, "out of host memory");
+  p->device = device;
+  p->kind = mesh->problem;
+  Slab &s = p->s;
+  s.dim[0] = M; s.dim[1] = N; s.dim[2] = P;
+  s.ks = mesh->ks; s.ke = mesh->ke; s.cks = mesh->cks;
+  s.nsd = nsd; s.dof = dof;
+  // element ownership of the reference (DMDAGetElementsCorners/Sizes): an element belongs to
+  // the rank that owns its upper node layer -> layers [ks-1, ke-1), rank 0 starts at 0.
+  s.els = mesh->ks > 0 ? mesh->ks - 1 : 0;
+  s.ele = mesh->ke - 1;
+  s.mat_e_ks = s.els;
+  s.before0 = 0;
+  s.before0 = (nsd == 3) ? pairs_before(s, 0, 0, s.ks) : pairs_before(s, 0, s.ks, 0);
+  p->cke = mesh->cke;
+
+  const int64_t plane = (nsd == 3) ? M * N : M;             // nodes per layer
+  const int64_t eplane = (nsd == 3) ? (M - 1) * (N - 1) : (M - 1);
+  p->nnodes = plane * (s.ke - s.ks);
+  p->nrows = p->nnodes * dof;
+  p->nnz = layer_nnz(s, s.ks, s.ke);
+  p->nel = eplane * (s.ele - s.els);
+  if (p->nel < 0) p->nel = 0;
+
+  int rc = 0;
+  auto cleanup = [&]() { femasm_plan_destroy(p); return rc; };
+#define PCHK(call)                                                                                   \
+  do {                                                                                               \
+    hipError_t e_ = (call);                                                                          \
+    if (e_ != hipSuccess) {                                                                          \
+      rc = fail(FEMASM_ERR_HIP, "%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+      return cleanup();                                                                              \
+    }                                                                                                \
+  } while (0)
+
+  PCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  p->own_stream = true;
+  for (auto &e : p->ev) PCHK(hipEventCreate(&e));
+
+  // coordinates
+  p->coords_user = mesh->coords;
+  p->ncoord = plane * (mesh->cke - mesh->cks) * nsd;
+  if (is_device_ptr(mesh->coords)) {
+    p->coords = mesh->coords;
+  } else {
+    PCHK(hipMalloc(&p->coords_dev, p->ncoord * sizeof(double)));
+    PCHK(hipMemcpyAsync(p->coords_dev, mesh->coords, p->ncoord * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    p->coords = p->coords_dev;
+  }
+
+  PCHK(hipMalloc(&p->rowptr, (p->nrows + 1) * sizeof(int64_t)));
+  PCHK(hipMalloc(&p->colidx, (size_t)(p->nnz > 0 ? p->nnz : 1) * sizeof(int32_t)));
+  PCHK(hipMalloc(&p->bad, sizeof(unsigned long long)));
+  PCHK(hipMemsetAsync(p->bad, 0, sizeof(unsigned long long), p->stream));
+  PCHK(hipMalloc(&p->elemF, (size_t)(p->nel > 0 ? p->nel : 1) * nfe * sizeof(double)));
+
+  // interface buffers: rows of node layer ks-1 (owed to the rank below) and of ke-1 (owed to us)
+  if (s.ks > 0) {
+    p->send_nnz = layer_nnz(s, s.ks - 1, s.ks);
+    p->send_count = p->send_nnz + plane * dof;
+    PCHK(hipMalloc(&p->send, p->send_count * sizeof(double)));
+  }
+  if (s.ke < SL) {
+    p->recv_nnz = layer_nnz(s, s.ke - 1, s.ke);
+    p->recv_count = p->recv_nnz + plane * dof;
+    PCHK(hipMalloc(&p->recv, p->recv_count * sizeof(double)));
+  }
+
+  hipLaunchKernelGGL(k_pattern, dim3(nblk(p->nrows + 1)), dim3(256), 0, p->stream, s, p->nrows, p->rowptr, p->colidx);
+  PCHK(hipGetLastError());
+  PCHK(hipStreamSynchronize(p->stream));
+#undef PCHK
+  *out = p;
+  return FEMASM_OK;
+}
+
+int femasm_plan_destroy(femasm_plan *p) {
+  if (!p) return FEMASM_OK;
+  (void)hipSetDevice(p->device);
+  if (p->stream) (void)hipStreamSynchronize(p->stream);
+  void *bufs[] = {p->coords_dev, p->rowptr, p->colidx, p->elemF, p->send, p->recv, p->bad,
+                  p->stage_vals, p->stage_b, p->stage_gp};
+  for (void *b : bufs)
+    if (b) (void)hipFree(b);
+  for (auto &e : p->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
+  delete p;
+  return FEMASM_OK;
+}
+
+int femasm_plan_set_stream(femasm_plan *p, void *stream) {
+  if (!p) return fail(FEMASM_ERR_ARG, "null plan");
+  HIPCHK(hipSetDevice(p->device));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
+  p->stream = (hipStream_t)stream;
+  p->own_stream = false;
+  return FEMASM_OK;
+}
+
+int femasm_plan_sync(femasm_plan *p) {
+  if (!p) return fail(FEMASM_ERR_ARG, "null plan");
+  HIPCHK(hipSetDevice(p->device));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  return FEMASM_OK;
+}
+
+int femasm_pattern(femasm_plan *p, int64_t *nrows, int64_t *nnz, const int64_t **rowptr, const int32_t **colidx) {
+  if (!p) return fail(FEMASM_ERR_ARG, "null plan");
+  if (nrows) *nrows = p->nrows;
+  if (nnz) *nnz = p->nnz;
+  if (rowptr) *rowptr = p->rowptr;
+  if (colidx) *colidx = p->colidx;
+  return FEMASM_OK;
+}
+
+int femasm_pattern_copy(femasm_plan *p, int64_t *rowptr, int32_t *colidx) {
+  if (!p) return fail(FEMASM_ERR_ARG, "null plan");
+  HIPCHK(hipSetDevice(p->device));
+  if (rowptr) HIPCHK(hipMemcpy(rowptr, p->rowptr, (p->nrows + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+  if (colidx) HIPCHK(hipMemcpy(colidx, p->colidx, p->nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return FEMASM_OK;
+}
+
+int femasm_scatter_map(femasm_plan *p, int64_t *map_out) {
+  if (!p || !map_out) return fail(FEMASM_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(p->device));
+  int nsd, dof, nen, ngp, nfe;
+  traits_of(p->kind, nsd, dof, nen, ngp, nfe);
+  const int nr = nen * dof;
+  const int64_t total = p->nel * nr * nr;
+  if (total == 0) return FEMASM_OK;
+  int64_t *dst = map_out;
+  const bool dev = is_device_ptr(map_out);
+  if (!dev) HIPCHK(hipMalloc(&dst, total * sizeof(int64_t)));
+  hipLaunchKernelGGL(k_scatter_map, dim3(nblk(p->nel * nr)), dim3(256), 0, p->stream, p->s, p->nel, nen, dst);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+  if (e == hipSuccess && !dev) e = hipMemcpy(map_out, dst, total * sizeof(int64_t), hipMemcpyDeviceToHost);
+  if (!dev) (void)hipFree(dst);
+  if (e != hipSuccess) return fail(FEMASM_ERR_HIP, "femasm_scatter_map: %s", hipGetErrorString(e));
+  return FEMASM_OK;
+}
+
+int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const femasm_bc *bcs, double *csr_values,
+                           double *b, femasm_stats *stats) {
+  if (!p) return fail(FEMASM_ERR_ARG, "null plan");
+  HIPCHK(hipSetDevice(p->device));
+  const auto t_begin = std::chrono::steady_clock::now();
+  const int bc = bcs ? bcs->kind : FEMASM_BC_NONE;
+  const Slab &s = p->s;
+  int nsd, dof, nen, ngp, nfe;
+  traits_of(p->kind, nsd, dof, nen, ngp, nfe);
+
+  // argument checks, before anything is launched
+  if (bc < 0 || bc > 3) return fail(FEMASM_ERR_ARG, "unknown bc kind %d", bc);
+  if ((bc == FEMASM_BC_POISSON_INLOOP && p->kind != KIND_POISSON) ||
+      (bc == FEMASM_BC_E2_COMPRESSION && p->kind != KIND_PLANE) ||
+      (bc == FEMASM_BC_S3_ALLFACES_EXACT && p->kind != KIND_ELASTIC))
+    return fail(FEMASM_ERR_ARG, "bc kind %d does not belong to problem kind %d", bc, p->kind);
+  femasm_material mloc{};
+  if (p->kind != KIND_POISSON) {
+    if (!mat) return fail(FEMASM_ERR_ARG, "material is required for elastic problems");
+    mloc = *mat;
+    if (mloc.layout == FEMASM_MAT_AOS) {
+      const int need = (p->kind == KIND_PLANE) ? 24 : 400;
+      if (!mloc.gp) return fail(FEMASM_ERR_ARG, "material.gp is null");
+      if (mloc.stride < need) return fail(FEMASM_ERR_ARG, "material stride %d < %d", mloc.stride, need);
+      if (mloc.e_ks > s.els) return fail(FEMASM_ERR_ARG, "material starts at element layer %lld > %lld",
+                                         (long long)mloc.e_ks, (long long)s.els);
+    } else if (mloc.layout != FEMASM_MAT_UNIFORM) {
+      return fail(FEMASM_ERR_ARG, "unknown material layout %d", mloc.layout);
+    }
+    p->s.mat_e_ks = (mloc.layout == FEMASM_MAT_AOS) ? mloc.e_ks : s.els;
+  } else {
+    mloc.layout = FEMASM_MAT_UNIFORM;
+  }
+
+  // host-side callers: stage inputs/outputs through device buffers
+  double ms_staging = 0.0;
+  const bool vals_host = csr_values && !is_device_ptr(csr_values);
+  const bool b_host = b && !is_device_ptr(b);
+  double *d_vals = csr_values, *d_b = b;
+  auto t0 = std::chrono::steady_clock::now();
+  if (vals_host) {
+    if (!p->stage_vals) HIPCHK(hipMalloc(&p->stage_vals, (size_t)(p->nnz > 0 ? p->nnz : 1) * sizeof(double)));
+    d_vals = p->stage_vals;
+  }
+  if (b_host) {
+    if (!p->stage_b) HIPCHK(hipMalloc(&p->stage_b, (size_t)p->nrows * sizeof(double)));
+    d_b = p->stage_b;
+  }
+  if (p->stage_gp) { (void)hipFree(p->stage_gp); p->stage_gp = nullptr; }
+  if (mloc.layout == FEMASM_MAT_AOS && p->kind != KIND_POISSON && !is_device_ptr(mloc.gp)) {
+    const int64_t eplane = (nsd == 3) ? (s.dim[0] - 1) * (s.dim[1] - 1) : (s.dim[0] - 1);
+    const int64_t cnt = eplane * (s.ele - mloc.e_ks) * mloc.stride;
+    if (cnt > 0) {
+      HIPCHK(hipMalloc(&p->stage_gp, cnt * sizeof(double)));
+      HIPCHK(hipMemcpyAsync(p->stage_gp, mloc.gp, cnt * sizeof(double), hipMemcpyHostToDevice, p->stream));
+      HIPCHK(hipStreamSynchronize(p->stream));
+    }
+  }
+  ms_staging += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+
+  HIPCHK(hipMemsetAsync(p->bad, 0, sizeof(unsigned long long), p->stream));
+
+  int rc = 0;
+  // ---- K ----
+  if (stats) HIPCHK(hipEventRecord(p->ev[0], p->stream));
+  if (d_vals) {
+    switch (p->kind) {
+      case KIND_POISSON: rc = launch_K<KIND_POISSON>(p, &mloc, bc, d_vals, s.ks, s.ke, 0); break;
+      case KIND_PLANE:   rc = launch_K<KIND_PLANE>(p, &mloc, bc, d_vals, s.ks, s.ke, 0); break;
+      case KIND_ELASTIC: rc = launch_K<KIND_ELASTIC>(p, &mloc, bc, d_vals, s.ks, s.ke, 0); break;
+    }
+    if (rc) return rc;
+    if (s.ks > 0) {  // partial rows of node layer ks-1, owed to the rank below
+      switch (p->kind) {
+        case KIND_POISSON: rc = launch_K<KIND_POISSON>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1); break;
+        case KIND_PLANE:   rc = launch_K<KIND_PLANE>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1); break;
+        case KIND_ELASTIC: rc = launch_K<KIND_ELASTIC>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1); break;
+      }
+      if (rc) return rc;
+    }
+  }
+  if (stats) HIPCHK(hipEventRecord(p->ev[1], p->stream));
+  // ---- b ----
+  if (d_b) {
+    switch (p->kind) {
+      case KIND_POISSON: rc = launch_rhs<KIND_POISSON>(p, &mloc, bc, d_b, s.ks, s.ke, 0, true); break;
+      case KIND_PLANE:   rc = launch_rhs<KIND_PLANE>(p, &mloc, bc, d_b, s.ks, s.ke, 0, true); break;
+      case KIND_ELASTIC: rc = launch_rhs<KIND_ELASTIC>(p, &mloc, bc, d_b, s.ks, s.ke, 0, true); break;
+    }
+    if (rc) return rc;
+    if (s.ks > 0) {
+      double *sb = p->send + p->send_nnz;
+      switch (p->kind) {
+        case KIND_POISSON: rc = launch_rhs<KIND_POISSON>(p, &mloc, bc, sb, s.ks - 1, s.ks, 1, false); break;
+        case KIND_PLANE:   rc = launch_rhs<KIND_PLANE>(p, &mloc, bc, sb, s.ks - 1, s.ks, 1, false); break;
+        case KIND_ELASTIC: rc = launch_rhs<KIND_ELASTIC>(p, &mloc, bc, sb, s.ks - 1, s.ks, 1, false); break;
+      }
+      if (rc) return rc;
+    }
+  }
+  if (stats) HIPCHK(hipEventRecord(p->ev[2], p->stream));
+
+  t0 = std::chrono::steady_clock::now();
+  if (vals_host) HIPCHK(hipMemcpyAsync(csr_values, d_vals, p->nnz * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  if (b_host) HIPCHK(hipMemcpyAsync(b, d_b, p->nrows * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  unsigned long long bad = 0;
+  HIPCHK(hipMemcpyAsync(&bad, p->bad, sizeof bad, hipMemcpyDeviceToHost, p->stream));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  if (vals_host || b_host)
+    ms_staging += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+
+  if (stats) {
+    float k_ms = 0, r_ms = 0;
+    HIPCHK(hipEventElapsedTime(&k_ms, p->ev[0], p->ev[1]));
+    HIPCHK(hipEventElapsedTime(&r_ms, p->ev[1], p->ev[2]));
+    stats->ms_kernel_K = k_ms;
+    stats->ms_kernel_rhs = r_ms;
+    stats->ms_staging = ms_staging;
+    stats->nel = p->nel;
+    stats->nrows = p->nrows;
+    stats->nnz = p->nnz;
+    stats->bad_detJ = (int64_t)bad;
+    const bool has_mat = p->kind != KIND_POISSON;
+    const bool aos = has_mat && mloc.layout == FEMASM_MAT_AOS;
+    stats->bytes_K = 8.0 * p->nnz + 8.0 * nsd * p->nnodes + (has_mat ? 16.0 * ngp * p->nel : 0.0);
+    stats->bytes_system = stats->bytes_K + 8.0 * p->nrows + (aos ? 8.0 * dof * ngp * p->nel : 0.0) +
+                          ((aos && p->kind == KIND_ELASTIC) ? 8.0 * 264 * p->nel : 0.0);
+    stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  }
+  if (bad) return fail(FEMASM_ERR_GEOMETRY, "%llu Gauss points with non-positive or NaN det(J)", bad);
+  return FEMASM_OK;
+}
+
+int femasm_interface_buffers(femasm_plan *p, double **send_buf, int64_t *send_count, double **recv_buf,
+                             int64_t *recv_count) {
+  if (!p) return fail(FEMASM_ERR_ARG, "null plan");
+  if (send_buf) *send_buf = p->send;
+  if (send_count) *send_count = p->send_count;
+  if (recv_buf) *recv_buf = p->recv;
+  if (recv_count) *recv_count = p->recv_count;
+  return FEMASM_OK;
+}
+
+int femasm_interface_apply(femasm_plan *p, const femasm_bc *bcs, double *csr_values, double *b) {
+  if (!p) return fail(FEMASM_ERR_ARG, "null plan");
+  if (!p->recv) return FEMASM_OK;  // top slab: nothing is owed to us
+  HIPCHK(hipSetDevice(p->device));
+  if ((csr_values && !is_device_ptr(csr_values)) || (b && !is_device_ptr(b)))
+    return fail(FEMASM_ERR_ARG, "femasm_interface_apply needs device-resident csr_values / b");
+  const int bc = bcs ? bcs->kind : FEMASM_BC_NONE;
+  const int64_t plane = (p->s.nsd == 3) ? p->s.dim[0] * p->s.dim[1] : p->s.dim[0];
+  hipLaunchKernelGGL(k_iface_apply, dim3(nblk(plane * p->s.dof)), dim3(256), 0, p->stream, p->s, bc, csr_values, b,
+                     p->recv, p->recv + p->recv_nnz);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(p->stream));
+  return FEMASM_OK;
+}
+
+int femasm_compress_bc_rows(femasm_plan *p, const femasm_bc *bcs, const double *csr_values, int64_t *rowptr_out,
+                            int32_t *colidx_out, double *values_out, int64_t *nnz_out) {
+  if (!p || !csr_values || !rowptr_out || !colidx_out || !values_out || !nnz_out)
+    return fail(FEMASM_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(p->device));
+  const int bc = bcs ? bcs->kind : FEMASM_BC_NONE;
+  const bool in_dev = is_device_ptr(csr_values);
+  const bool out_dev = is_device_ptr(rowptr_out) && is_device_ptr(colidx_out) && is_device_ptr(values_out);
+  const bool out_host = !is_device_ptr(rowptr_out) && !is_device_ptr(colidx_out) && !is_device_ptr(values_out);
+  if (!out_dev && !out_host) return fail(FEMASM_ERR_ARG, "outputs must be all host or all device");
+
+  const int64_t nrows = p->nrows, nnz = p->nnz;
+  int rc = FEMASM_OK;
+  double *d_in = nullptr, *d_vals = nullptr;
+  int64_t *d_len = nullptr, *d_rp = nullptr;
+  int32_t *d_ci = nullptr;
+  void *d_tmp = nullptr;
+  size_t tmp_bytes = 0;
+  hipError_t e = hipSuccess;
+#define CCHK(call) do { if (e == hipSuccess) e = (call); } while (0)
+  if (!in_dev) {
+    CCHK(hipMalloc(&d_in, nnz * sizeof(double)));
+    CCHK(hipMemcpy(d_in, csr_values, nnz * sizeof(double), hipMemcpyHostToDevice));
+  }
+  const double *vin = in_dev ? csr_values : d_in;
+  CCHK(hipMalloc(&d_len, (nrows + 1) * sizeof(int64_t)));
+  if (out_dev) { d_rp = rowptr_out; d_ci = colidx_out; d_vals = values_out; }
+  else {
+    CCHK(hipMalloc(&d_rp, (nrows + 1) * sizeof(int64_t)));
+    CCHK(hipMalloc(&d_ci, nnz * sizeof(int32_t)));
+    CCHK(hipMalloc(&d_vals, nnz * sizeof(double)));
+  }
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_bc_rowlen, dim3(nblk(nrows + 1)), dim3(256), 0, p->stream, p->s, bc, nrows, p->rowptr, d_len);
+    CCHK(hipGetLastError());
+    CCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_len, d_rp, (int)(nrows + 1), p->stream));
+    CCHK(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
+    CCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_len, d_rp, (int)(nrows + 1), p->stream));
+  }
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_bc_compress, dim3(nblk(nrows)), dim3(256), 0, p->stream, p->s, bc, nrows, p->rowptr,
+                       p->colidx, vin, d_rp, d_ci, d_vals);
+    CCHK(hipGetLastError());
+  }
+  int64_t newnnz = 0;
+  CCHK(hipMemcpyAsync(&newnnz, d_rp + nrows, sizeof(int64_t), hipMemcpyDeviceToHost, p->stream));
+  CCHK(hipStreamSynchronize(p->stream));
+  if (e == hipSuccess && out_host) {
+    CCHK(hipMemcpy(rowptr_out, d_rp, (nrows + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+    CCHK(hipMemcpy(colidx_out, d_ci, newnnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+    CCHK(hipMemcpy(values_out, d_vals, newnnz * sizeof(double), hipMemcpyDeviceToHost));
+  }
+#undef CCHK
+  if (d_in) (void)hipFree(d_in);
+  if (d_len) (void)hipFree(d_len);
+  if (d_tmp) (void)hipFree(d_tmp);
+  if (out_host) {
+    if (d_rp) (void)hipFree(d_rp);
+    if (d_ci) (void)hipFree(d_ci);
+    if (d_vals) (void)hipFree(d_vals);
+  }
+  if (e != hipSuccess) rc = fail(FEMASM_ERR_HIP, "femasm_compress_bc_rows: %s", hipGetErrorString(e));
+  *nnz_out = newnnz;
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,849 @@
+// femasm_kernels.h -- hand-written gfx950 (CDNA4, wave64) kernels of the assembly engine.
+//
+// Design (DESIGN.md has the long form):
+//  * K kernel = deterministic GATHER.  A workgroup owns a brick of 64 nodes and the
+//    (halo'd) brick of elements around it.  Per Gauss point, the first NE threads build
+//    one geometry record per element (physical shape-function gradients + w*detJ-scaled
+//    material coefficients) into LDS, double-buffered; then every thread contracts the
+//    records of the elements that touch ITS node into register accumulators.
+//    A thread is (node, type): the 4 waves of the workgroup are the 4 combinations
+//    (element layer below/above the node) x (lower/upper face of that element) in the
+//    slowest direction, so each thread owns one third of its node's stencil
+//    (3^(nsd-1) neighbour blocks of dof x dof), accumulates 2^(nsd-1) elements x
+//    2^(nsd-1) local nodes, and no CSR entry is ever touched by two threads except the
+//    middle third, whose two halves are summed in a fixed order through LDS.
+//    Every CSR value is written exactly once and never read: traffic = algorithmic bytes.
+//  * The element->nonzero scatter map is the closed form of femasm_device.h.
+//  * RHS = per-element Fe/Ge into a small scratch array, then a per-node gather in the
+//    reference's element order (k->j->i).
+#pragma once
+#include "femasm_device.h"
+
+namespace femasm {
+
+enum { KIND_POISSON = 0, KIND_PLANE = 1, KIND_ELASTIC = 2 };
+enum { BC_NONE = 0, BC_POISSON = 1, BC_E2 = 2, BC_S3 = 3 };
+
+template <int KIND> struct Traits;
+template <> struct Traits<KIND_POISSON> {
+  static constexpr int NSD = 3, DOF = 1, NEN = 8, NGP = 8, NCOEF = 1;
+  static constexpr int BX = 4, BY = 4, BZ = 4;
+  static constexpr int NFE = 8;  // doubles of per-element RHS scratch
+};
+template <> struct Traits<KIND_PLANE> {
+  static constexpr int NSD = 2, DOF = 2, NEN = 4, NGP = 4, NCOEF = 3;
+  static constexpr int BX = 16, BY = 4, BZ = 1;
+  static constexpr int NFE = 8;
+};
+template <> struct Traits<KIND_ELASTIC> {
+  static constexpr int NSD = 3, DOF = 3, NEN = 8, NGP = 8, NCOEF = 3;
+  static constexpr int BX = 4, BY = 4, BZ = 4;
+  static constexpr int NFE = 48;  // Fe[24] then Ge[24]
+};
+
+// ---------------------------------------------------------------------------
+// Reference-element tables, evaluated at compile time in the reference's operation
+// order (A1, A2, A5): literal abscissa 0.57735026919, unit weights.
+// ---------------------------------------------------------------------------
+constexpr double GAUSS_G = 0.57735026919;
+constexpr double HSX[8] = {-1, -1, 1, 1, -1, -1, 1, 1};
+constexpr double HSY[8] = {-1, 1, 1, -1, -1, 1, 1, -1};
+constexpr double HSZ[8] = {-1, -1, -1, -1, 1, 1, 1, 1};
+constexpr double QSX[4] = {-1, -1, 1, 1};
+constexpr double QSY[4] = {-1, 1, 1, -1};
+
+struct Tab3 {
+  double G[8][3][8];   // dN_n/dxi_k at Gauss point p : G[p][k][n]
+  double N[8][8];      // N_n at Gauss point p
+  double NF[24][8];    // N_n at face Gauss point p (S3:253-289)
+};
+struct Tab2 {
+  double G[4][2][4];
+  double N[4][4];
+};
+
+constexpr Tab3 make_tab3() {
+  Tab3 t{};
+  for (int p = 0; p < 8; p++) {
+    const double xi = HSX[p] * GAUSS_G, eta = HSY[p] * GAUSS_G, zeta = HSZ[p] * GAUSS_G;
+    for (int n = 0; n < 8; n++) {
+      const double ax = 1.0 + HSX[n] * xi, ay = 1.0 + HSY[n] * eta, az = 1.0 + HSZ[n] * zeta;
+      t.G[p][0][n] = (HSX[n] * 0.125) * ay * az;
+      t.G[p][1][n] = (HSY[n] * 0.125) * ax * az;
+      t.G[p][2][n] = (HSZ[n] * 0.125) * ax * ay;
+      t.N[p][n] = 0.125 * ax * ay * az;
+    }
+  }
+  const double s0[4] = {-1, 1, -1, 1}, s1[4] = {-1, -1, 1, 1};
+  for (int f = 0; f < 6; f++) {
+    const int axis = f / 2;
+    const double side = (f % 2 == 0) ? 1.0 : -1.0;
+    const int a0 = (axis == 0) ? 1 : 0, a1 = (axis == 2) ? 1 : 2;
+    for (int q = 0; q < 4; q++) {
+      double x[3] = {0, 0, 0};
+      x[axis] = side;
+      x[a0] = s0[q] * GAUSS_G;
+      x[a1] = s1[q] * GAUSS_G;
+      for (int n = 0; n < 8; n++)
+        t.NF[4 * f + q][n] = 0.125 * (1.0 + HSX[n] * x[0]) * (1.0 + HSY[n] * x[1]) * (1.0 + HSZ[n] * x[2]);
+    }
+  }
+  return t;
+}
+constexpr Tab2 make_tab2() {
+  Tab2 t{};
+  for (int p = 0; p < 4; p++) {
+    const double xi = QSX[p] * GAUSS_G, eta = QSY[p] * GAUSS_G;
+    for (int n = 0; n < 4; n++) {
+      t.G[p][0][n] = (QSX[n] * 0.25) * (1.0 + QSY[n] * eta);
+      t.G[p][1][n] = (QSY[n] * 0.25) * (1.0 + QSX[n] * xi);
+      t.N[p][n] = 0.25 * (1.0 + QSX[n] * xi) * (1.0 + QSY[n] * eta);
+    }
+  }
+  return t;
+}
+
+__constant__ Tab3 c_tab3 = make_tab3();
+__constant__ Tab2 c_tab2 = make_tab2();
+
+// ---------------------------------------------------------------------------
+struct KArgs {
+  const double *coords;   // node layers [cks, cke)
+  const double *gp;       // material AoS (may be null for uniform / Poisson)
+  double *out;            // CSR values of the processed rows
+  unsigned long long *bad;  // det(J) <= 0 counter
+  int64_t base_off;       // row_start of the first processed row (subtracted)
+  int64_t cke;            // one past the last coords layer
+  int64_t s0, s1;         // processed node layers of the slowest direction
+  double E, nu;           // uniform material
+  int32_t mat_layout, mat_stride;
+  int32_t bc;             // BC_* kind
+  int32_t iface;          // 1: interface pass (elastic BC rows become zero rows)
+};
+
+// isotropic coefficient triple scaled by w*detJ, in the reference's operation order
+template <int KIND>
+__device__ inline void scaled_coefs(double E, double nu, double wJ, double &d11, double &d12, double &d44) {
+  if constexpr (KIND == KIND_PLANE) {  // E2:297-305
+    const double factor = E / ((1.0 + nu) * (1.0 - 2.0 * nu));
+    d11 = factor * (1.0 - nu) * 1.0 * wJ;
+    d12 = factor * nu * 1.0 * wJ;
+    d44 = factor * (0.5 * (1.0 - 2.0 * nu)) * 1.0 * wJ;
+  } else {                             // S3:487-500
+    const double factor = E * (1 - nu) / ((1.0 + nu) * (1.0 - 2.0 * nu));
+    d11 = factor * 1.0 * 1.0 * wJ;
+    d12 = factor * (nu / (1 - nu)) * 1.0 * wJ;
+    d44 = factor * (0.5 * (1 - 2 * nu) / (1 - nu)) * 1.0 * wJ;
+  }
+}
+
+// 3x3 Jacobian, its inverse and determinant in the reference's order (A3, A4)
+struct Jac3 { double iJ[3][3]; double det; };
+__device__ inline Jac3 jac3(const double (*G)[8], const double *xc /*[8][3]*/) {
+  double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+  for (int n = 0; n < 8; n++)
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) J[r][c] = J[r][c] + G[r][n] * xc[3 * n + c];
+  Jac3 o;
+  const double t4 = J[2][0] * J[0][1], t6 = J[2][0] * J[0][2], t8 = J[1][0] * J[0][1];
+  const double t10 = J[1][0] * J[0][2], t12 = J[0][0] * J[1][1], t14 = J[0][0] * J[1][2];
+  const double t17 = 1.0 / (t4 * J[1][2] - t6 * J[1][1] - t8 * J[2][2] + t10 * J[2][1] + t12 * J[2][2] - t14 * J[2][1]);
+  o.iJ[0][0] = (J[1][1] * J[2][2] - J[1][2] * J[2][1]) * t17;
+  o.iJ[0][1] = -(J[0][1] * J[2][2] - J[0][2] * J[2][1]) * t17;
+  o.iJ[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * t17;
+  o.iJ[1][0] = -(-J[2][0] * J[1][2] + J[1][0] * J[2][2]) * t17;
+  o.iJ[1][1] = (-t6 + J[0][0] * J[2][2]) * t17;
+  o.iJ[1][2] = -(-t10 + t14) * t17;
+  o.iJ[2][0] = (-J[2][0] * J[1][1] + J[1][0] * J[2][1]) * t17;
+  o.iJ[2][1] = -(-t4 + J[0][0] * J[2][1]) * t17;
+  o.iJ[2][2] = (-t8 + t12) * t17;
+  o.det = J[0][0] * J[1][1] * J[2][2] - J[0][0] * J[1][2] * J[2][1] - J[1][0] * J[0][1] * J[2][2] +
+          J[1][0] * J[0][2] * J[2][1] + J[2][0] * J[0][1] * J[1][2] - J[2][0] * J[0][2] * J[1][1];
+  return o;
+}
+__device__ inline double det3_only(const double (*G)[8], const double *xc) {
+  double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+  for (int n = 0; n < 8; n++)
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) J[r][c] = J[r][c] + G[r][n] * xc[3 * n + c];
+  return J[0][0] * J[1][1] * J[2][2] - J[0][0] * J[1][2] * J[2][1] - J[1][0] * J[0][1] * J[2][2] +
+         J[1][0] * J[0][2] * J[2][1] + J[2][0] * J[0][1] * J[1][2] - J[2][0] * J[0][2] * J[1][1];
+}
+struct Jac2 { double i00, i01, i10, i11, det; };
+__device__ inline Jac2 jac2(const double (*G)[4], const double *xc /*[4][2]*/) {
+  double J00 = 0, J01 = 0, J10 = 0, J11 = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    J00 = J00 + G[0][i] * xc[2 * i];
+    J01 = J01 + G[0][i] * xc[2 * i + 1];
+    J10 = J10 + G[1][i] * xc[2 * i];
+    J11 = J11 + G[1][i] * xc[2 * i + 1];
+  }
+  Jac2 o;
+  o.det = (J00 * J11) - (J01 * J10);
+  o.i00 = J11 / o.det;
+  o.i01 = -J01 / o.det;
+  o.i10 = -J10 / o.det;
+  o.i11 = J00 / o.det;
+  return o;
+}
+
+// ---------------------------------------------------------------------------
+// contraction of one (a,b) node pair at one Gauss point into a dof x dof block
+// ---------------------------------------------------------------------------
+template <int KIND, int D>
+__device__ inline void add_block(double *acc, const double *l, const double *m, const double *q, const double *gb) {
+  if constexpr (KIND == KIND_POISSON) {
+    // l = w*detJ * grad N_a   (P3:279: Ke += g.g * w * J)
+    double v = acc[0];
+#pragma unroll
+    for (int k = 0; k < 3; k++) v = fma(l[k], gb[k], v);
+    acc[0] = v;
+  } else {
+    // B^T D B with isotropic D (E2:285-320, S3:470-515), zeros of B and D skipped:
+    //   K[i][j] += D12 ga_i gb_j + D44 ga_j gb_i            (i != j)
+    //   K[i][i] += D11 ga_i gb_i + D44 sum_{k!=i} ga_k gb_k
+#pragma unroll
+    for (int i = 0; i < D; i++)
+#pragma unroll
+      for (int j = 0; j < D; j++) {
+        double v = acc[i * D + j];
+        if (i != j) {
+          v = fma(l[i], gb[j], v);
+          v = fma(m[j], gb[i], v);
+        } else {
+          v = fma(q[i], gb[i], v);
+#pragma unroll
+          for (int k = 0; k < D; k++)
+            if (k != i) v = fma(m[k], gb[k], v);
+        }
+        acc[i * D + j] = v;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// small index helpers
+// ---------------------------------------------------------------------------
+constexpr int HDI[8] = {0, 0, 1, 1, 0, 0, 1, 1};
+constexpr int HDJ[8] = {0, 1, 1, 0, 0, 1, 1, 0};
+constexpr int HDK[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+constexpr int QDI[4] = {0, 0, 1, 1};
+constexpr int QDJ[4] = {0, 1, 1, 0};
+
+__device__ inline bool on_boundary(const Slab &s, int64_t i, int64_t j, int64_t k) {
+  bool b = (i == 0) || (i == s.dim[0] - 1) || (j == 0) || (j == s.dim[1] - 1);
+  if (s.nsd == 3) b = b || (k == 0) || (k == s.dim[2] - 1);
+  return b;
+}
+// is (node, any dof) a Dirichlet row of this BC kind
+__device__ inline bool is_bc_node(const Slab &s, int bc, int64_t i, int64_t j, int64_t k) {
+  if (bc == BC_POISSON || bc == BC_S3) return on_boundary(s, i, j, k);
+  if (bc == BC_E2) return (i == 0) || (i == s.dim[0] - 1);
+  return false;
+}
+
+// ---------------------------------------------------------------------------
+// K kernel
+// ---------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(256, 2) void k_assemble_rows(const Slab s, const KArgs a) {
+  using T = Traits<KIND>;
+  constexpr int NSD = T::NSD, DOF = T::DOF, NEN = T::NEN, NGP = T::NGP, NCOEF = T::NCOEF;
+  constexpr int BX = T::BX, BY = T::BY, BZ = T::BZ;
+  constexpr int EX = BX + 1, EY = BY + 1, EZ = (NSD == 3) ? BZ + 1 : 1;
+  constexpr int CX = BX + 2, CY = BY + 2, CZ = (NSD == 3) ? BZ + 2 : 1;
+  constexpr int NE = EX * EY * EZ, NC = CX * CY * CZ;
+  constexpr int REC = NSD * NEN + NCOEF;
+  constexpr int DD = DOF * DOF;
+  constexpr int NBLK = (NSD == 3) ? 9 : 3;  // neighbour blocks per thread
+  constexpr int NACC = NBLK * DD;
+  constexpr int XSTR = NACC | 1;            // odd exchange stride: no LDS bank conflicts
+  static_assert(BX * BY * BZ == 64, "a brick is one wave of nodes");
+  static_assert(NE <= 256, "one geometry thread per element");
+  static_assert(64 * XSTR <= 2 * NE * REC, "exchange area aliases the record buffers");
+
+  __shared__ double sh_x[NC * NSD];
+  __shared__ double sh_rec[2 * NE * REC];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int type = tid >> 6;            // wave-uniform: 0..3
+  const int oes = (type < 2) ? -1 : 0;  // element layer relative to the node (slowest direction)
+  const int obs = type & 1;             // which face of that element (slowest direction)
+  const int as = -oes;                  // this node's position in that element (slowest direction)
+
+  // ---- brick -> global ----------------------------------------------------
+  const int64_t M = s.dim[0], N = s.dim[1], P = s.dim[2];
+  const int64_t nbx = (M + BX - 1) / BX;
+  const int64_t bid = blockIdx.x;
+  int64_t g0x, g0y, g0z;  // global index of the brick's first node
+  int lx, ly, lz;
+  if constexpr (NSD == 3) {
+    const int64_t nby = (N + BY - 1) / BY;
+    g0x = (bid % nbx) * BX;
+    g0y = ((bid / nbx) % nby) * BY;
+    g0z = a.s0 + (bid / (nbx * nby)) * BZ;
+    lx = lane & 3; ly = (lane >> 2) & 3; lz = lane >> 4;
+  } else {
+    g0x = (bid % nbx) * BX;
+    g0y = a.s0 + (bid / nbx) * BY;
+    g0z = 0;
+    lx = lane & 15; ly = lane >> 4; lz = 0;
+  }
+
+  // ---- stage the brick's node coordinates in LDS (clamped reads: elements that would
+  //      use a clamped node are masked out below) -------------------------------------
+  for (int q = tid; q < NC; q += 256) {
+    const int cx = q % CX, cy = (q / CX) % CY, cz = q / (CX * CY);
+    int64_t gi = g0x - 1 + cx, gj = g0y - 1 + cy, gk = g0z - 1 + cz;
+    gi = gi < 0 ? 0 : (gi > M - 1 ? M - 1 : gi);
+    int64_t node;
+    if constexpr (NSD == 3) {
+      gj = gj < 0 ? 0 : (gj > N - 1 ? N - 1 : gj);
+      gk = gk < s.cks ? s.cks : (gk > a.cke - 1 ? a.cke - 1 : gk);
+      node = gi + M * (gj + N * (gk - s.cks));
+    } else {
+      gj = gj < s.cks ? s.cks : (gj > a.cke - 1 ? a.cke - 1 : gj);
+      node = gi + M * (gj - s.cks);
+    }
+#pragma unroll
+    for (int d = 0; d < NSD; d++) sh_x[q * NSD + d] = a.coords[node * NSD + d];
+  }
+
+  // ---- geometry-thread set-up: thread tid < NE owns element tid of the halo'd brick ----
+  const bool gthread = tid < NE;
+  const int ex = tid % EX, ey = (tid / EX) % EY, ez = tid / (EX * EY);
+  bool eexists = false;
+  int64_t emat = 0;
+  if (gthread) {
+    const int64_t gex = g0x - 1 + ex, gey = g0y - 1 + ey, gez = g0z - 1 + ez;
+    if constexpr (NSD == 3) {
+      eexists = gex >= 0 && gex < M - 1 && gey >= 0 && gey < N - 1 && gez >= s.els && gez < s.ele;
+      emat = gex + (M - 1) * (gey + (N - 1) * (gez - s.mat_e_ks));
+    } else {
+      eexists = gex >= 0 && gex < M - 1 && gey >= s.els && gey < s.ele;
+      emat = gex + (M - 1) * (gey - s.mat_e_ks);
+    }
+  }
+  __syncthreads();
+
+  // one geometry record: grad N_b (physical) for the NEN nodes, then the w*detJ-scaled coefficients
+  auto geometry = [&](int p, double *recbuf) {
+    if (!gthread) return;
+    double *r = recbuf + tid * REC;
+    if (!eexists) {
+#pragma unroll
+      for (int q = 0; q < REC; q++) r[q] = 0.0;
+      return;
+    }
+    double xc[NEN * NSD];
+    double wJ;
+    if constexpr (NSD == 3) {
+#pragma unroll
+      for (int n = 0; n < 8; n++) {
+        const int cn = (ex + HDI[n]) + CX * ((ey + HDJ[n]) + CY * (ez + HDK[n]));
+#pragma unroll
+        for (int d = 0; d < 3; d++) xc[3 * n + d] = sh_x[3 * cn + d];
+      }
+      const double(*G)[8] = c_tab3.G[p];
+      const Jac3 jj = jac3(G, xc);
+#pragma unroll
+      for (int n = 0; n < 8; n++)
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+          r[3 * n + k] = G[0][n] * jj.iJ[k][0] + G[1][n] * jj.iJ[k][1] + G[2][n] * jj.iJ[k][2];
+      wJ = 1.0 * jj.det;
+    } else {
+#pragma unroll
+      for (int n = 0; n < 4; n++) {
+        const int cn = (ex + QDI[n]) + CX * (ey + QDJ[n]);
+        xc[2 * n] = sh_x[2 * cn];
+        xc[2 * n + 1] = sh_x[2 * cn + 1];
+      }
+      const double(*G)[4] = c_tab2.G[p];
+      const Jac2 jj = jac2(G, xc);
+#pragma unroll
+      for (int n = 0; n < 4; n++) {
+        r[2 * n] = G[0][n] * jj.i00 + G[1][n] * jj.i01;
+        r[2 * n + 1] = G[0][n] * jj.i10 + G[1][n] * jj.i11;
+      }
+      wJ = 1.0 * jj.det;
+    }
+    if (!(wJ > 0.0)) atomicAdd(a.bad, 1ULL);
+    if constexpr (KIND == KIND_POISSON) {
+      r[NSD * NEN] = wJ;
+    } else {
+      double E = a.E, nu = a.nu;
+      if (a.mat_layout == 0) {
+        constexpr int offE = (KIND == KIND_PLANE) ? 8 : 96, offNu = (KIND == KIND_PLANE) ? 12 : 104;
+        const double *q = a.gp + emat * a.mat_stride;
+        E = q[offE + p];
+        nu = q[offNu + p];
+      }
+      scaled_coefs<KIND>(E, nu, wJ, r[NSD * NEN], r[NSD * NEN + 1], r[NSD * NEN + 2]);
+    }
+  };
+
+  double acc[NACC];
+#pragma unroll
+  for (int q = 0; q < NACC; q++) acc[q] = 0.0;
+
+  // contraction of the records that touch this thread's node, for its third of the stencil
+  auto contract = [&](const double *recbuf) {
+    if constexpr (NSD == 3) {
+      const int ezl = lz + 1 + oes;
+#pragma unroll
+      for (int oy = -1; oy <= 0; oy++)
+#pragma unroll
+        for (int ox = -1; ox <= 0; ox++) {
+          const double *r = recbuf + ((lx + 1 + ox) + EX * ((ly + 1 + oy) + EY * ezl)) * REC;
+          const double *ra = r + (4 * as + quad_idx(-ox, -oy)) * 3;
+          double l[3], m[3], q[3];
+          if constexpr (KIND == KIND_POISSON) {
+            const double wJ = r[24];
+#pragma unroll
+            for (int k = 0; k < 3; k++) l[k] = ra[k] * wJ;
+          } else {
+            const double d11 = r[24], d12 = r[25], d44 = r[26];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+              l[k] = d12 * ra[k];
+              m[k] = d44 * ra[k];
+              q[k] = d11 * ra[k];
+            }
+          }
+#pragma unroll
+          for (int by = 0; by <= 1; by++)
+#pragma unroll
+            for (int bx = 0; bx <= 1; bx++) {
+              const double *rb = r + (4 * obs + quad_idx(bx, by)) * 3;
+              const double gb[3] = {rb[0], rb[1], rb[2]};
+              add_block<KIND, DOF>(acc + ((oy + by + 1) * 3 + (ox + bx + 1)) * DD, l, m, q, gb);
+            }
+        }
+    } else {
+      const int eyl = ly + 1 + oes;
+#pragma unroll
+      for (int ox = -1; ox <= 0; ox++) {
+        const double *r = recbuf + ((lx + 1 + ox) + EX * eyl) * REC;
+        // local index of (bx, by): bx == 0 ? by : 3 - by
+        const double *ra = r + ((ox == 0) ? as : 3 - as) * 2;
+        const double d11 = r[8], d12 = r[9], d44 = r[10];
+        double l[2], m[2], q[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          l[k] = d12 * ra[k];
+          m[k] = d44 * ra[k];
+          q[k] = d11 * ra[k];
+        }
+#pragma unroll
+        for (int bx = 0; bx <= 1; bx++) {
+          const double *rb = r + ((bx == 0) ? obs : 3 - obs) * 2;
+          const double gb[2] = {rb[0], rb[1]};
+          add_block<KIND, DOF>(acc + (ox + bx + 1) * DD, l, m, q, gb);
+        }
+      }
+    }
+  };
+
+  // ---- Gauss-point pipeline: records of point p+1 are built while point p is contracted ----
+  geometry(0, sh_rec);
+  __syncthreads();
+  for (int p = 0; p < NGP; p++) {
+    if (p + 1 < NGP) geometry(p + 1, sh_rec + ((p + 1) & 1) * (NE * REC));
+    contract(sh_rec + (p & 1) * (NE * REC));
+    __syncthreads();
+  }
+
+  // ---- middle third: lower-layer half (type 1) + upper-layer half (type 2), fixed order ----
+  double *exch = sh_rec;
+  if (type == 1) {
+#pragma unroll
+    for (int q = 0; q < NACC; q++) exch[lane * XSTR + q] = acc[q];
+  }
+  __syncthreads();
+  if (type == 1) return;
+  if (type == 2) {
+#pragma unroll
+    for (int q = 0; q < NACC; q++) acc[q] = exch[lane * XSTR + q] + acc[q];
+  }
+
+  // ---- write this thread's third of its node's rows: each CSR value exactly once ----
+  const int64_t i = g0x + lx, j = g0y + ly, k = g0z + lz;
+  const int ds = oes + obs;  // -1, 0, +1 : neighbour layer in the slowest direction
+  bool valid;
+  int64_t sl, SL;            // index / extent of the slowest direction
+  if constexpr (NSD == 3) { valid = i < M && j < N && k < a.s1; sl = k; SL = P; }
+  else                    { valid = i < M && j < a.s1;          sl = j; SL = N; }
+  if (!valid || sl + ds < 0 || sl + ds > SL - 1) return;
+
+  const bool isbc = is_bc_node(s, a.bc, i, j, k);
+  double bcdiag = a.iface ? 0.0 : 1.0;
+  if (KIND == KIND_POISSON && isbc) {
+    // _ZERO_ROW_i then ADD: the diagonal becomes the number of (assembled) elements sharing the node
+    const int vx = (i > 0) + (i < M - 1), vy = (j > 0) + (j < N - 1);
+    const int vz = (k - 1 >= s.els && k - 1 < s.ele) + (k >= s.els && k < s.ele);
+    bcdiag = (double)(vx * vy * vz);
+  }
+  const int cntx = span1(i, M), xi0 = (i == 0);
+  const int si = ds + 1 - (sl == 0);
+  const int64_t rs0 = row_start(s, i, j, k, 0) - a.base_off;
+  if constexpr (NSD == 3) {
+    const int cnty = span1(j, N), yi0 = (j == 0);
+    const int cnt = cntx * cnty * span1(k, P);
+#pragma unroll
+    for (int c = 0; c < DOF; c++) {
+      double *row = a.out + rs0 + (int64_t)c * DOF * cnt;
+#pragma unroll
+      for (int dy = -1; dy <= 1; dy++) {
+        if (j + dy < 0 || j + dy > N - 1) continue;
+#pragma unroll
+        for (int dx = -1; dx <= 1; dx++) {
+          if (i + dx < 0 || i + dx > M - 1) continue;
+          const int idx = (si * cnty + (dy + 1 - yi0)) * cntx + (dx + 1 - xi0);
+#pragma unroll
+          for (int cc = 0; cc < DOF; cc++) {
+            double v = acc[((dy + 1) * 3 + (dx + 1)) * DD + c * DOF + cc];
+            if (isbc) v = (ds == 0 && dy == 0 && dx == 0 && cc == c) ? bcdiag : 0.0;
+            row[DOF * idx + cc] = v;
+          }
+        }
+      }
+    }
+  } else {
+    const int cnt = cntx * span1(j, N);
+#pragma unroll
+    for (int c = 0; c < DOF; c++) {
+      double *row = a.out + rs0 + (int64_t)c * DOF * cnt;
+#pragma unroll
+      for (int dx = -1; dx <= 1; dx++) {
+        if (i + dx < 0 || i + dx > M - 1) continue;
+        const int idx = si * cntx + (dx + 1 - xi0);
+#pragma unroll
+        for (int cc = 0; cc < DOF; cc++) {
+          double v = acc[(dx + 1) * DD + c * DOF + cc];
+          if (isbc) v = (ds == 0 && dx == 0 && cc == c) ? bcdiag : 0.0;
+          row[DOF * idx + cc] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// RHS, pass 1: one thread per assembled element -> Fe (and Ge) in the scratch array
+// ---------------------------------------------------------------------------
+struct RArgs {
+  const double *coords;
+  const double *gp;
+  double *elemF;          // [nel_local][NFE]
+  double *out;            // b of the processed rows
+  const double *recv;     // interface_apply
+  int64_t cke;
+  int64_t s0, s1;
+  int64_t nel;            // assembled elements
+  int32_t mat_layout, mat_stride;
+  int32_t bc, iface;
+};
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k_rhs_elem(const Slab s, const RArgs a) {
+  using T = Traits<KIND>;
+  constexpr int NFE = T::NFE;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= a.nel) return;
+  const int64_t M = s.dim[0], N = s.dim[1];
+  const int64_t mx = M - 1, my = N - 1;
+  double F[NFE];
+#pragma unroll
+  for (int q = 0; q < NFE; q++) F[q] = 0.0;
+
+  if constexpr (KIND == KIND_PLANE) {
+    const int64_t ex = e % mx, ey = s.els + e / mx;
+    double xc[8];
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+      const int64_t node = (ex + QDI[n]) + M * (ey + QDJ[n] - s.cks);
+      xc[2 * n] = a.coords[2 * node];
+      xc[2 * n + 1] = a.coords[2 * node + 1];
+    }
+    if (a.mat_layout == 0) {
+      const double *q = a.gp + (ex + mx * (ey - s.mat_e_ks)) * a.mat_stride;
+      for (int p = 0; p < 4; p++) {  // E2:339-349
+        const Jac2 jj = jac2(c_tab2.G[p], xc);
+        const double fac = 1.0 * jj.det;
+        const double fx = q[16 + p], fy = q[20 + p];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          F[2 * i] += fac * c_tab2.N[p][i] * fx;
+          F[2 * i + 1] += fac * c_tab2.N[p][i] * fy;
+        }
+      }
+    }
+  } else {
+    const int64_t ex = e % mx, ey = (e / mx) % my, ez = s.els + e / (mx * my);
+    double xc[24];
+#pragma unroll
+    for (int n = 0; n < 8; n++) {
+      const int64_t node = (ex + HDI[n]) + M * ((ey + HDJ[n]) + N * (ez + HDK[n] - s.cks));
+#pragma unroll
+      for (int d = 0; d < 3; d++) xc[3 * n + d] = a.coords[3 * node + d];
+    }
+    if constexpr (KIND == KIND_POISSON) {
+      constexpr double PI = 3.14159265358979323846264338327950288;
+      for (int p = 0; p < 8; p++) {  // P3:549-566
+        const double fac = 1.0 * det3_only(c_tab3.G[p], xc);
+        double pos[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int n = 0; n < 8; n++)
+#pragma unroll
+          for (int d = 0; d < 3; d++) pos[d] += c_tab3.N[p][n] * xc[3 * n + d];
+        const double fv = 3.0 * PI * PI * sin(PI * pos[0]) * sin(PI * pos[1]) * sin(PI * pos[2]);
+#pragma unroll
+        for (int i = 0; i < 8; i++) F[i] += fac * fv * c_tab3.N[p][i];
+      }
+    } else if (a.mat_layout == 0) {
+      const double *q = a.gp + (ex + mx * (ey + my * (ez - s.mat_e_ks))) * a.mat_stride;
+      for (int p = 0; p < 8; p++) {  // S3:534-545
+        const double fac = 1.0 * det3_only(c_tab3.G[p], xc);
+        const double fx = q[160 + p], fy = q[168 + p], fz = q[176 + p];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          F[3 * i] += fac * c_tab3.N[p][i] * fx;
+          F[3 * i + 1] += fac * c_tab3.N[p][i] * fy;
+          F[3 * i + 2] += fac * c_tab3.N[p][i] * fz;
+        }
+      }
+      // natural-BC face integral over all six faces of every element, S3:548-656
+      const double dx = fabs(xc[0] - xc[9]), dy = fabs(xc[1] - xc[4]), dz = fabs(xc[2] - xc[14]);
+      const double *gx = q + 184, *gy = q + 256, *gz = q + 328, *EB = q + 112, *nuB = q + 136;
+      for (int p = 0; p < 24; p++) {
+        const double pe = EB[p], pn = nuB[p];
+        const double factor = pe * (1 - pn) / ((1.0 + pn) * (1.0 - 2.0 * pn));
+        const double d11 = factor * 1.0, d12 = factor * (pn / (1 - pn)), d44 = factor * (0.5 * (1 - 2 * pn) / (1 - pn));
+        const double e0 = gx[3 * p], e1 = gy[3 * p + 1], e2 = gz[3 * p + 2];
+        const double e3 = gx[3 * p + 1] + gy[3 * p], e4 = gy[3 * p + 2] + gz[3 * p + 1], e5 = gx[3 * p + 2] + gz[3 * p];
+        const double z0 = d11 * e0 + d12 * e1 + d12 * e2;
+        const double z1 = d12 * e0 + d11 * e1 + d12 * e2;
+        const double z2 = d12 * e0 + d12 * e1 + d11 * e2;
+        const double z3 = d44 * e3, z4 = d44 * e4, z5 = d44 * e5;
+        const int axis = p / 8;
+        const double side = ((p / 4) % 2 == 0) ? 1.0 : -1.0;
+        double sn[3], Jp;
+        if (axis == 0)      { sn[0] = z0 * side; sn[1] = z3 * side; sn[2] = z5 * side; Jp = (0.5 * dy) * (0.5 * dz); }
+        else if (axis == 1) { sn[0] = z3 * side; sn[1] = z1 * side; sn[2] = z4 * side; Jp = (0.5 * dx) * (0.5 * dz); }
+        else                { sn[0] = z5 * side; sn[1] = z4 * side; sn[2] = z2 * side; Jp = (0.5 * dx) * (0.5 * dy); }
+        const double fac = 1.0 * Jp;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const double w = fac * c_tab3.NF[p][i];
+          F[24 + 3 * i] += w * sn[0];
+          F[24 + 3 * i + 1] += w * sn[1];
+          F[24 + 3 * i + 2] += w * sn[2];
+        }
+      }
+    }
+  }
+  double *o = a.elemF + e * NFE;
+#pragma unroll
+  for (int q = 0; q < NFE; q++) o[q] = F[q];
+}
+
+// ---------------------------------------------------------------------------
+// RHS, pass 2: one thread per node; contributions added in the reference's element
+// order (k -> j -> i), Fe before Ge (S3:787-788); then the Dirichlet value.
+// ---------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(256) void k_rhs_gather(const Slab s, const RArgs a) {
+  using T = Traits<KIND>;
+  constexpr int NSD = T::NSD, DOF = T::DOF, NFE = T::NFE;
+  const int64_t M = s.dim[0], N = s.dim[1];
+  const int64_t mx = M - 1, my = N - 1;
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t nn = (NSD == 3) ? M * N * (a.s1 - a.s0) : M * (a.s1 - a.s0);
+  if (q >= nn) return;
+  int64_t i = q % M, j, k;
+  if constexpr (NSD == 3) { j = (q / M) % N; k = a.s0 + q / (M * N); }
+  else                    { j = a.s0 + q / M; k = 0; }
+
+  double b[DOF];
+#pragma unroll
+  for (int c = 0; c < DOF; c++) b[c] = 0.0;
+
+  if constexpr (NSD == 3) {
+    for (int oz = -1; oz <= 0; oz++)
+      for (int oy = -1; oy <= 0; oy++)
+        for (int ox = -1; ox <= 0; ox++) {
+          const int64_t ex = i + ox, ey = j + oy, ez = k + oz;
+          if (ex < 0 || ex >= mx || ey < 0 || ey >= my || ez < s.els || ez >= s.ele) continue;
+          const double *F = a.elemF + (ex + mx * (ey + my * (ez - s.els))) * NFE;
+          const int al = hex_idx(-ox, -oy, -oz);
+#pragma unroll
+          for (int c = 0; c < DOF; c++) b[c] = b[c] + F[al * DOF + c];
+          if constexpr (KIND == KIND_ELASTIC) {
+#pragma unroll
+            for (int c = 0; c < DOF; c++) b[c] = b[c] + F[24 + al * DOF + c];
+          }
+        }
+  } else {
+    for (int oy = -1; oy <= 0; oy++)
+      for (int ox = -1; ox <= 0; ox++) {
+        const int64_t ex = i + ox, ey = j + oy;
+        if (ex < 0 || ex >= mx || ey < s.els || ey >= s.ele) continue;
+        const double *F = a.elemF + (ex + mx * (ey - s.els)) * NFE;
+        const int al = quad_idx(-ox, -oy);
+#pragma unroll
+        for (int c = 0; c < DOF; c++) b[c] = b[c] + F[al * DOF + c];
+      }
+  }
+
+  if (is_bc_node(s, a.bc, i, j, k)) {
+    if (a.iface) {
+      // partial sums owed to the rank below: Dirichlet rows are ignored by the receiver
+#pragma unroll
+      for (int c = 0; c < DOF; c++) b[c] = 0.0;
+    } else if (a.bc == BC_POISSON) {
+      b[0] = 0.0;                                   // P3:624-630
+    } else if (a.bc == BC_E2) {
+      b[0] = (i == M - 1) ? -1.0 : 1.0;             // E2:882-885
+      if constexpr (DOF > 1) b[1] = 0.0;
+    } else if (a.bc == BC_S3) {
+      constexpr double PI = 3.14159265358979323846264338327950288;
+      const int64_t node = i + M * (j + N * (k - s.cks));
+      const double x = a.coords[3 * node], y = a.coords[3 * node + 1], z = a.coords[3 * node + 2];
+      b[0] = 0.0;                                   // S3:964-968 via S3:1501-1505
+      if constexpr (DOF > 2) { b[1] = 0.0; b[2] = sin(PI * x) * sin(PI * y) * sin(PI * z); }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < DOF; c++) a.out[q * DOF + c] = b[c];
+}
+
+// ---------------------------------------------------------------------------
+// interface apply: own + received, one thread per row of the top owned node layer
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_iface_apply(const Slab s, int bc, double *vals, double *b,
+                                                     const double *recvK, const double *recvB) {
+  const int64_t M = s.dim[0], N = s.dim[1];
+  const int64_t layer = s.ke - 1;
+  const int64_t nnode = (s.nsd == 3) ? M * N : M;
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= nnode * s.dof) return;
+  const int c = (int)(r % s.dof);
+  const int64_t q = r / s.dof;
+  int64_t i = q % M, j, k;
+  if (s.nsd == 3) { j = q / M; k = layer; } else { j = layer; k = 0; }
+  if (bc != BC_POISSON && is_bc_node(s, bc, i, j, k)) return;
+  const int64_t cnt = (int64_t)span1(i, s.dim[0]) * span1(j, s.dim[1]) * span1(k, s.dim[2]) * s.dof;
+  const int64_t rs = row_start(s, i, j, k, c);
+  const int64_t i0 = 0, j0 = (s.nsd == 3) ? 0 : layer, k0 = (s.nsd == 3) ? layer : 0;
+  const int64_t rs_recv = rs - row_start(s, i0, j0, k0, 0);
+  if (vals && recvK)
+    for (int64_t t = 0; t < cnt; t++) vals[rs + t] = vals[rs + t] + recvK[rs_recv + t];
+  if (b && recvB) {
+    const int64_t lr = (q + nnode * (layer - s.ks)) * s.dof + c;
+    b[lr] = b[lr] + recvB[q * s.dof + c];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// pattern (A12) and explicit scatter map (A13)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pattern(const Slab s, int64_t nrows, int64_t *rowptr, int32_t *colidx) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r > nrows) return;
+  const int64_t M = s.dim[0], N = s.dim[1], P = s.dim[2];
+  const int64_t first = (s.nsd == 3) ? M * N * s.ks : M * s.ks;  // first owned node
+  if (r == nrows) {
+    // one past the last owned layer: pre1() clamps, so this is the slab's stored-entry count
+    const int64_t j = (s.nsd == 3) ? 0 : s.ke, k = (s.nsd == 3) ? s.ke : 0;
+    rowptr[r] = (int64_t)s.dof * s.dof * (pairs_before(s, 0, j, k) - s.before0);
+    return;
+  }
+  const int c = (int)(r % s.dof);
+  const int64_t n = first + r / s.dof;
+  const int64_t i = n % M, j = (n / M) % N, k = n / (M * N);
+  int64_t pos = row_start(s, i, j, k, c);
+  rowptr[r] = pos;
+  for (int64_t kk = (k > 0 ? k - 1 : 0); kk <= (k < P - 1 ? k + 1 : P - 1); kk++)
+    for (int64_t jj = (j > 0 ? j - 1 : 0); jj <= (j < N - 1 ? j + 1 : N - 1); jj++)
+      for (int64_t ii = (i > 0 ? i - 1 : 0); ii <= (i < M - 1 ? i + 1 : M - 1); ii++)
+        for (int cc = 0; cc < s.dof; cc++) colidx[pos++] = (int32_t)(s.dof * (ii + M * (jj + N * kk)) + cc);
+}
+
+// one thread per (element, local row); writes the nen*dof positions of that row
+__global__ __launch_bounds__(256) void k_scatter_map(const Slab s, int64_t nel, int nen, int64_t *map) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int nr = nen * s.dof;
+  if (t >= nel * nr) return;
+  const int64_t e = t / nr;
+  const int r = (int)(t % nr), ar = r / s.dof, cr = r % s.dof;
+  const int64_t M = s.dim[0], N = s.dim[1];
+  const int64_t mx = M - 1, my = N - 1;
+  int64_t ex, ey, ez;
+  if (s.nsd == 3) { ex = e % mx; ey = (e / mx) % my; ez = s.els + e / (mx * my); }
+  else            { ex = e % mx; ey = s.els + e / mx; ez = 0; }
+  const int di = (s.nsd == 3) ? HDI[ar] : QDI[ar], dj = (s.nsd == 3) ? HDJ[ar] : QDJ[ar];
+  const int dk = (s.nsd == 3) ? HDK[ar] : 0;
+  const int64_t i = ex + di, j = ey + dj, k = ez + dk;
+  const int64_t sl = (s.nsd == 3) ? k : j;
+  int64_t *o = map + t * nr;
+  if (sl < s.ks || sl >= s.ke) {
+    for (int q = 0; q < nr; q++) o[q] = -1;
+    return;
+  }
+  const int64_t rs = row_start(s, i, j, k, cr);
+  const int cntx = span1(i, s.dim[0]), cnty = span1(j, s.dim[1]);
+  for (int q = 0; q < nr; q++) {
+    const int ac = q / s.dof, cc = q % s.dof;
+    const int ci = (s.nsd == 3) ? HDI[ac] : QDI[ac], cj = (s.nsd == 3) ? HDJ[ac] : QDJ[ac];
+    const int ck = (s.nsd == 3) ? HDK[ac] : 0;
+    const int dx = ci - di, dy = cj - dj, dz = ck - dk;
+    const int xi = dx + 1 - (i == 0), yi = dy + 1 - (j == 0), zi = (s.nsd == 3) ? dz + 1 - (k == 0) : 0;
+    o[q] = rs + (int64_t)s.dof * ((zi * cnty + yi) * cntx + xi) + cc;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// PETSc's truncated MatZeroRows storage
+// ---------------------------------------------------------------------------
+__device__ inline bool is_bc_row(const Slab &s, int bc, int64_t r /*local row*/) {
+  const int64_t M = s.dim[0], N = s.dim[1];
+  const int64_t first = (s.nsd == 3) ? M * N * s.ks : M * s.ks;
+  const int64_t n = first + r / s.dof;
+  return is_bc_node(s, bc, n % M, (n / M) % N, n / (M * N));
+}
+__global__ __launch_bounds__(256) void k_bc_rowlen(const Slab s, int bc, int64_t nrows, const int64_t *rowptr,
+                                                   int64_t *len) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r > nrows) return;
+  len[r] = (r == nrows) ? 0 : (is_bc_row(s, bc, r) ? 1 : rowptr[r + 1] - rowptr[r]);
+}
+__global__ __launch_bounds__(256) void k_bc_compress(const Slab s, int bc, int64_t nrows, const int64_t *rowptr,
+                                                     const int32_t *colidx, const double *vals,
+                                                     const int64_t *rowptr_new, int32_t *colidx_new,
+                                                     double *vals_new) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= nrows) return;
+  const int64_t M = s.dim[0], N = s.dim[1];
+  const int64_t first = (s.nsd == 3) ? M * N * s.ks : M * s.ks;
+  int64_t o = rowptr_new[r];
+  if (is_bc_row(s, bc, r)) {
+    colidx_new[o] = (int32_t)(first * s.dof + r);
+    vals_new[o] = 1.0;
+    return;
+  }
+  for (int64_t q = rowptr[r]; q < rowptr[r + 1]; q++, o++) {
+    colidx_new[o] = colidx[q];
+    vals_new[o] = vals[q];
+  }
+}
+
+}  // namespace femasm

@@ -1,0 +1,208 @@
+"""Host-side binding of the femasm C ABI (include/femasm.h) for Python callers.
+
+This is plumbing only: the product is libfemasm.so (hand-written gfx950 kernels behind a
+plain C ABI).  The binding mirrors the reference drivers' call sites --
+``AssembleA_* + AssembleF_* (+ DMDABCApplyCompression)`` become one
+``Plan.assemble_system`` call (P3:675-678, E2:692-700, S3:1384-1392).
+
+There is NO CPU path: if libfemasm.so is missing, or no HIP device is present, every
+compute entry point raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libfemasm.so")
+
+POISSON3D_Q1, PLANE_STRAIN2D_Q1, ELASTIC3D_Q1 = 0, 1, 2
+MAT_AOS, MAT_UNIFORM = 0, 1
+BC_NONE, BC_POISSON_INLOOP, BC_E2_COMPRESSION, BC_S3_ALLFACES_EXACT = 0, 1, 2, 3
+
+_TRAITS = {  # kind: (nsd, dof, nen, ngp)
+    POISSON3D_Q1: (3, 1, 8, 8),
+    PLANE_STRAIN2D_Q1: (2, 2, 4, 4),
+    ELASTIC3D_Q1: (3, 3, 8, 8),
+}
+
+EXPORTS = [
+    "femasm_plan_create", "femasm_plan_destroy", "femasm_plan_set_stream", "femasm_pattern",
+    "femasm_pattern_copy", "femasm_scatter_map", "femasm_assemble_system", "femasm_interface_buffers",
+    "femasm_interface_apply", "femasm_compress_bc_rows", "femasm_plan_sync", "femasm_last_error",
+    "femasm_version",
+]
+
+
+class FemasmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"femasm error {code}: {msg}")
+        self.code = code
+
+
+class Mesh(C.Structure):
+    _fields_ = [("problem", C.c_int32), ("reserved", C.c_int32), ("M", C.c_int64), ("N", C.c_int64),
+                ("P", C.c_int64), ("ks", C.c_int64), ("ke", C.c_int64), ("cks", C.c_int64), ("cke", C.c_int64),
+                ("coords", C.c_void_p)]
+
+
+class Material(C.Structure):
+    _fields_ = [("layout", C.c_int32), ("stride", C.c_int32), ("e_ks", C.c_int64), ("gp", C.c_void_p),
+                ("E", C.c_double), ("nu", C.c_double)]
+
+
+class Quad(C.Structure):
+    _fields_ = [("ngp", C.c_int32), ("rule", C.c_int32)]
+
+
+class BC(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("ms_total", C.c_double), ("ms_kernel_K", C.c_double), ("ms_kernel_rhs", C.c_double),
+                ("ms_staging", C.c_double), ("bytes_K", C.c_double), ("bytes_system", C.c_double),
+                ("nel", C.c_int64), ("nrows", C.c_int64), ("nnz", C.c_int64), ("bad_detJ", C.c_int64)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def load():
+    """Load libfemasm.so; raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; "
+                                    "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        lib.femasm_last_error.restype = C.c_char_p
+        lib.femasm_version.restype = C.c_char_p
+        for name in EXPORTS:
+            getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        _lib = lib
+    return _lib
+
+
+def _ptr(x):
+    """Address of a numpy array (host) or a torch tensor (host or device); None -> NULL."""
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        assert x.flags["C_CONTIGUOUS"]
+        return C.c_void_p(x.ctypes.data)
+    if hasattr(x, "data_ptr"):
+        assert x.is_contiguous()
+        return C.c_void_p(x.data_ptr())
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    raise TypeError(type(x))
+
+
+def _check(rc):
+    if rc != 0:
+        raise FemasmError(rc, load().femasm_last_error().decode())
+
+
+class Plan:
+    """One slab of the structured (DMDA) mesh on one GPU."""
+
+    def __init__(self, problem, M, N, P=1, coords=None, ks=0, ke=None, cks=None, cke=None, device=0):
+        lib = load()
+        nsd, dof, nen, ngp = _TRAITS[problem]
+        SL = P if nsd == 3 else N
+        ke = SL if ke is None else ke
+        cks = (max(ks - 1, 0)) if cks is None else cks
+        cke = (min(ke + 1, SL)) if cke is None else cke
+        self.problem, self.M, self.N, self.P = problem, M, N, (P if nsd == 3 else 1)
+        self.nsd, self.dof, self.nen, self.ngp = nsd, dof, nen, ngp
+        self.ks, self.ke, self.cks, self.cke = ks, ke, cks, cke
+        self._coords = coords  # keep alive
+        mesh = Mesh(problem, 0, M, N, self.P, ks, ke, cks, cke, _ptr(coords))
+        quad = Quad(ngp, 0)
+        h = C.c_void_p()
+        _check(lib.femasm_plan_create(C.byref(mesh), C.byref(quad), C.c_int(device), C.byref(h)))
+        self._h = h
+        nrows, nnz = C.c_int64(), C.c_int64()
+        rp, ci = C.c_void_p(), C.c_void_p()
+        _check(lib.femasm_pattern(self._h, C.byref(nrows), C.byref(nnz), C.byref(rp), C.byref(ci)))
+        self.nrows, self.nnz = nrows.value, nnz.value
+        self.rowptr_dev, self.colidx_dev = rp.value, ci.value
+        plane_e = (M - 1) * (N - 1) if nsd == 3 else (M - 1)
+        self.els = max(ks - 1, 0)
+        self.ele = ke - 1
+        self.nel = plane_e * max(self.ele - self.els, 0)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().femasm_plan_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_stream(self, stream_handle):
+        _check(load().femasm_plan_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def sync(self):
+        _check(load().femasm_plan_sync(self._h))
+
+    def pattern(self):
+        """(rowptr int64 [nrows+1], colidx int32 [nnz]) as host numpy arrays."""
+        rowptr = np.empty(self.nrows + 1, dtype=np.int64)
+        colidx = np.empty(self.nnz, dtype=np.int32)
+        _check(load().femasm_pattern_copy(self._h, _ptr(rowptr), _ptr(colidx)))
+        return rowptr, colidx
+
+    def scatter_map(self):
+        nr = self.nen * self.dof
+        out = np.empty(self.nel * nr * nr, dtype=np.int64)
+        _check(load().femasm_scatter_map(self._h, _ptr(out)))
+        return out.reshape(self.nel, nr, nr)
+
+    def assemble_system(self, values, b, material=None, bc=BC_NONE, E=0.0, nu=0.0, stride=0, e_ks=None,
+                        want_stats=False):
+        """values / b: numpy (host) or torch (device) float64 buffers, or None.
+        material: AoS GaussPointCoefficients array (numpy/torch) or None for uniform E, nu."""
+        if material is None:
+            mat = Material(MAT_UNIFORM, 0, 0, None, E, nu)
+        else:
+            mat = Material(MAT_AOS, stride, self.els if e_ks is None else e_ks, _ptr(material), E, nu)
+        bcs = BC(bc, 0)
+        st = Stats()
+        _check(load().femasm_assemble_system(self._h, C.byref(mat), C.byref(bcs), _ptr(values), _ptr(b),
+                                             C.byref(st) if want_stats else None))
+        return st if want_stats else None
+
+    def interface_buffers(self):
+        sb, rb = C.c_void_p(), C.c_void_p()
+        sc, rc = C.c_int64(), C.c_int64()
+        _check(load().femasm_interface_buffers(self._h, C.byref(sb), C.byref(sc), C.byref(rb), C.byref(rc)))
+        return (sb.value, sc.value), (rb.value, rc.value)
+
+    def interface_apply(self, values, b, bc=BC_NONE):
+        bcs = BC(bc, 0)
+        _check(load().femasm_interface_apply(self._h, C.byref(bcs), _ptr(values), _ptr(b)))
+
+    def compress_bc_rows(self, values, bc):
+        """PETSc's truncated MatZeroRows storage; host numpy in, host numpy out."""
+        rp = np.empty(self.nrows + 1, dtype=np.int64)
+        ci = np.empty(self.nnz, dtype=np.int32)
+        va = np.empty(self.nnz, dtype=np.float64)
+        n = C.c_int64()
+        bcs = BC(bc, 0)
+        _check(load().femasm_compress_bc_rows(self._h, C.byref(bcs), _ptr(values), _ptr(rp), _ptr(ci), _ptr(va),
+                                              C.byref(n)))
+        return rp, ci[:n.value].copy(), va[:n.value].copy()
+
+
+def dmda_slab_ranges(nlayers, nranks):
+    """PETSc DMDA split of `nlayers` node layers over `nranks`: P/p + (P%p > r) each."""
+    out, s = [], 0
+    for r in range(nranks):
+        n = nlayers // nranks + (1 if nlayers % nranks > r else 0)
+        out.append((s, s + n))
+        s += n
+    return out
