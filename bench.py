@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py -- global assembly throughput of the femasm engine on MI355X.
+
+A "step" is one pass of the hot path over one synthetic mesh already resident in HBM:
+K (CSR values) + b + Dirichlet rows of one `femasm_assemble_system` call (plus, for N > 1,
+the slab-interface exchange over RCCL and `femasm_interface_apply`).
+
+Default workload (N = 1): BASELINE.json's target configuration, SGFEM_elastic3D Q1 hex on a
+128^3 mesh (24x24 local matrices, E=90, nu=0.28, all-face Dirichlet).  For N GPUs the mesh is
+128 x 128 x (128*N) elements cut into N z-slabs by the DMDA rule (weak scaling; at N = 8 it has
+the element count of 256^3).  Other configurations: --workload poisson3d|elastic2d, --nel.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="elastic3d", choices=["elastic3d", "poisson3d", "elastic2d"])
+    ap.add_argument("--nel", type=int, default=0, help="elements per direction (default: 128 / 256 / 2048)")
+    ap.add_argument("--perturb", action="store_true", help="general (non-affine) geometry variant")
+    ap.add_argument("--uniform-material", action="store_true", help="uniform E,nu instead of the AoS array")
+    ap.add_argument("--strong", action="store_true", help="fixed global mesh split over N slabs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--k-only", action="store_true", help="time K assembly only (no b)")
+    return ap.parse_args()
+
+
+def cpu_baseline(workload):
+    """Serial CPU assembly (oracle = restatement of the reference's loops, 1 core) on a bounded
+    sample of the same workload.  This is the ONLY place bench.py touches oracle/."""
+    import numpy as np
+    from oracle import oracle as O
+    if workload == "elastic3d":
+        n = 32
+        M = n + 1
+        coords = O.uniform_coords(3, M, M, M)
+        props = O.props_s3(n, n, n, coords)
+        rp, ci = O.pattern(3, 3, M, M, M)
+        t0 = time.perf_counter()
+        K, b = O.assemble_elastic3d(M, M, M, coords, props, rp, ci)
+        O.bc_s3(M, M, M, coords, rp, ci, K, b)
+        dt = time.perf_counter() - t0
+        nel, sample = n ** 3, "32^3 sub-mesh of the 128^3 workload (K + b + BC), scaled per element"
+    elif workload == "poisson3d":
+        n = 64
+        M = n + 1
+        coords = O.uniform_coords(3, M, M, M)
+        rp, ci = O.pattern(3, 1, M, M, M)
+        t0 = time.perf_counter()
+        O.assemble_poisson3d(M, M, M, coords, rp, ci)
+        dt = time.perf_counter() - t0
+        nel, sample = n ** 3, "64^3 sub-mesh (K + b with in-loop BC)"
+    else:
+        n = 1024
+        M = n + 1
+        coords = O.uniform_coords(2, M, M)
+        props = O.props_e2(n, n, coords)
+        rp, ci = O.pattern(2, 2, M, M)
+        t0 = time.perf_counter()
+        K, b = O.assemble_elastic2d(M, M, coords, props, rp, ci)
+        O.bc_e2(M, M, rp, ci, K, b)
+        dt = time.perf_counter() - t0
+        nel, sample = n * n, "1024^2 sub-mesh (K + b + BC)"
+    return {"value": nel / dt, "unit": "elements/s", "cores": 1, "kind": "port", "sample": sample,
+            "seconds": round(dt, 3)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from petsc_amd import femasm as F
+    from petsc_amd import slab, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the femasm engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    wl = args.workload
+    if wl == "elastic3d":
+        kind, nsd, dof, ngp, bc, stride = F.ELASTIC3D_Q1, 3, 3, 8, F.BC_S3_ALLFACES_EXACT, 400
+        nel = args.nel or 128
+        ref = "SGFEM/SGFEM_elastic3D.cpp"
+    elif wl == "poisson3d":
+        kind, nsd, dof, ngp, bc, stride = F.POISSON3D_Q1, 3, 1, 8, F.BC_POISSON_INLOOP, 0
+        nel = args.nel or 256
+        ref = "FEM_poisson3D/FEM.cpp"
+    else:
+        kind, nsd, dof, ngp, bc, stride = F.PLANE_STRAIN2D_Q1, 2, 2, 4, F.BC_E2_COMPRESSION, 24
+        nel = args.nel or 2048
+        ref = "FEM_elsatic2D/FEM.cpp"
+
+    # global mesh: weak scaling stacks N copies of the single-GPU mesh along the slab direction
+    nslow = nel if args.strong else nel * world
+    M = N = nel + 1
+    if nsd == 3:
+        P, SL = nslow + 1, nslow + 1
+    else:
+        N, P, SL = nslow + 1, 1, nslow + 1
+    ks, ke = slab.slab_ranges(SL, world)[rank]
+    cks, cke = max(ks - 1, 0), min(ke + 1, SL)
+    els, ele = max(ks - 1, 0), ke - 1
+
+    coords = synth.uniform_coords(nsd, M, N, P, cks, cke, device=dev)
+    if args.perturb:
+        coords = synth.perturb_coords(coords, nsd, M, N, P, k0=cks)
+    material = None
+    E, nu = (90.0, 0.28) if wl == "elastic3d" else (1.0, 0.33)
+    if wl != "poisson3d" and not args.uniform_material:
+        if wl == "elastic3d":
+            material = synth.props_s3(M, N, P, coords, els, ele, ck0=cks, E=E, nu=nu)
+        else:
+            material = synth.props_e2(M, N, coords, els, ele, ck0=cks, E=E, nu=nu)
+
+    plan = F.Plan(kind, M, N, P, coords=coords, ks=ks, ke=ke, cks=cks, cke=cke, device=local_rank)
+    plan.set_stream(torch.cuda.current_stream().cuda_stream)
+    vals = torch.empty(plan.nnz, dtype=torch.float64, device=dev)
+    b = None if args.k_only else torch.empty(plan.nrows, dtype=torch.float64, device=dev)
+
+    send = recv = None
+    if world > 1:
+        (_, sc), (_, rc) = plan.interface_buffers()
+        send = torch.empty(max(sc, 1), dtype=torch.float64, device=dev)
+        recv = torch.empty(max(rc, 1), dtype=torch.float64, device=dev)
+        plan.interface_set_buffers(send if sc else None, recv if rc else None)
+
+    k_ms = []
+
+    def step(collect):
+        st = plan.assemble_system(vals, b, material=material, stride=stride, bc=bc, E=E, nu=nu, e_ks=els,
+                                  want_stats=True)
+        if world > 1:
+            slab.exchange_interface(send if rank > 0 else None, recv if rank < world - 1 else None, rank, world)
+            plan.interface_apply(vals, b, bc=bc)
+        if collect:
+            k_ms.append(st.ms_kernel_K)
+        return st
+
+    for _ in range(args.warmup):
+        st = step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    nel_local = torch.tensor([float(st.nel)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(nel_local, op=dist.ReduceOp.SUM)
+    dt = float(tmax.item())
+    nel_total = float(nel_local.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * dt / args.steps
+        k_avg_ms = sum(k_ms) / len(k_ms)
+        achieved = st.bytes_K / (k_avg_ms * 1e-3) / 1e9
+        kernel = {"elastic3d": "k_assemble_rows<ELASTIC3D>", "poisson3d": "k_assemble_rows<POISSON3D>",
+                  "elastic2d": "k_assemble_rows<PLANE_STRAIN2D>"}[wl]
+        out = {
+            "metric": "global assembly elements/sec + achieved HBM GB/s fraction",
+            "value": nel_total / (dt / args.steps),
+            "unit": "elements/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong" if args.strong else "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{ref} Q1 {wl} {nel}^{nsd} elements per GPU-slab x {world}"
+                            f"{' (general geometry)' if args.perturb else ' (uniform DMDA coordinates)'}, "
+                            f"K + b + Dirichlet rows{' (K only)' if args.k_only else ''}",
+                "global_elements": int(nel_total),
+                "rows_per_gpu": int(st.nrows),
+                "nnz_per_gpu": int(st.nnz),
+                "material": "uniform" if material is None else f"AoS GaussPointCoefficients stride {stride}",
+                "parallelism": f"z-slab x{world}, interface rows exchanged over RCCL p2p" if world > 1 else "1 GPU",
+            },
+            "roofline": {
+                "kernel": kernel,
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": st.bytes_K,
+                "avg_launch_ms": k_avg_ms,
+            },
+            "rhs_ms": st.ms_kernel_rhs,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl)
+        print(json.dumps(out), flush=True)
+    plan.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

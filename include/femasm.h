@@ -131,6 +131,9 @@ int femasm_assemble_system(femasm_plan *plan, const femasm_material *material, c
  * from rank+1 (RCCL/MPI).  Counts are in doubles; 0 where there is no neighbour. */
 int femasm_interface_buffers(femasm_plan *plan, double **send_buf, int64_t *send_count,
                              double **recv_buf, int64_t *recv_count);
+/* Use caller-owned DEVICE buffers (e.g. torch / PETSc device vectors registered with RCCL)
+ * of at least send_count / recv_count doubles instead of the plan's own; NULL keeps it. */
+int femasm_interface_set_buffers(femasm_plan *plan, double *send_buf, double *recv_buf);
 /* own + received, fixed order (deterministic); Dirichlet rows are left untouched. */
 int femasm_interface_apply(femasm_plan *plan, const femasm_bc *bc, double *csr_values, double *b);
 

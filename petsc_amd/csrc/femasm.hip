@@ -74,6 +74,7 @@ struct femasm_plan {
   // interface buffers (K rows of one node layer in CSR layout, then the b slice)
   double *send = nullptr, *recv = nullptr;
   int64_t send_count = 0, recv_count = 0, send_nnz = 0, recv_nnz = 0;
+  bool own_send = true, own_recv = true;
 
   unsigned long long *bad = nullptr;
   hipStream_t stream = nullptr;
@@ -276,8 +277,8 @@ int femasm_plan_destroy(femasm_plan *p) {
   if (!p) return FEMASM_OK;
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
-  void *bufs[] = {p->coords_dev, p->rowptr, p->colidx, p->elemF, p->send, p->recv, p->bad,
-                  p->stage_vals, p->stage_b, p->stage_gp};
+  void *bufs[] = {p->coords_dev, p->rowptr, p->colidx, p->elemF, p->own_send ? p->send : nullptr,
+                  p->own_recv ? p->recv : nullptr, p->bad, p->stage_vals, p->stage_b, p->stage_gp};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   for (auto &e : p->ev)
@@ -481,6 +482,25 @@ int femasm_interface_buffers(femasm_plan *p, double **send_buf, int64_t *send_co
   if (send_count) *send_count = p->send_count;
   if (recv_buf) *recv_buf = p->recv;
   if (recv_count) *recv_count = p->recv_count;
+  return FEMASM_OK;
+}
+
+int femasm_interface_set_buffers(femasm_plan *p, double *send_buf, double *recv_buf) {
+  if (!p) return fail(FEMASM_ERR_ARG, "null plan");
+  HIPCHK(hipSetDevice(p->device));
+  if ((send_buf && !is_device_ptr(send_buf)) || (recv_buf && !is_device_ptr(recv_buf)))
+    return fail(FEMASM_ERR_ARG, "interface buffers must be device memory");
+  HIPCHK(hipStreamSynchronize(p->stream));
+  if (send_buf && p->send_count > 0) {
+    if (p->own_send && p->send) (void)hipFree(p->send);
+    p->send = send_buf;
+    p->own_send = false;
+  }
+  if (recv_buf && p->recv_count > 0) {
+    if (p->own_recv && p->recv) (void)hipFree(p->recv);
+    p->recv = recv_buf;
+    p->own_recv = false;
+  }
   return FEMASM_OK;
 }
 

@@ -29,7 +29,7 @@ _TRAITS = {  # kind: (nsd, dof, nen, ngp)
 EXPORTS = [
     "femasm_plan_create", "femasm_plan_destroy", "femasm_plan_set_stream", "femasm_pattern",
     "femasm_pattern_copy", "femasm_scatter_map", "femasm_assemble_system", "femasm_interface_buffers",
-    "femasm_interface_apply", "femasm_compress_bc_rows", "femasm_plan_sync", "femasm_last_error",
+    "femasm_interface_set_buffers", "femasm_interface_apply", "femasm_compress_bc_rows", "femasm_plan_sync", "femasm_last_error",
     "femasm_version",
 ]
 
@@ -182,6 +182,10 @@ class Plan:
         _check(load().femasm_interface_buffers(self._h, C.byref(sb), C.byref(sc), C.byref(rb), C.byref(rc)))
         return (sb.value, sc.value), (rb.value, rc.value)
 
+    def interface_set_buffers(self, send, recv):
+        self._ifbufs = (send, recv)  # keep alive
+        _check(load().femasm_interface_set_buffers(self._h, _ptr(send), _ptr(recv)))
+
     def interface_apply(self, values, b, bc=BC_NONE):
         bcs = BC(bc, 0)
         _check(load().femasm_interface_apply(self._h, C.byref(bcs), _ptr(values), _ptr(b)))
@@ -196,13 +200,3 @@ class Plan:
         _check(load().femasm_compress_bc_rows(self._h, C.byref(bcs), _ptr(values), _ptr(rp), _ptr(ci), _ptr(va),
                                               C.byref(n)))
         return rp, ci[:n.value].copy(), va[:n.value].copy()
-
-
-def dmda_slab_ranges(nlayers, nranks):
-    """PETSc DMDA split of `nlayers` node layers over `nranks`: P/p + (P%p > r) each."""
-    out, s = [], 0
-    for r in range(nranks):
-        n = nlayers // nranks + (1 if nlayers % nranks > r else 0)
-        out.append((s, s + n))
-        s += n
-    return out

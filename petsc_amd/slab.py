@@ -1,0 +1,74 @@
+"""Host logic of the multi-GPU slab partition; no compute here.
+
+One process per GPU; GPU r owns the node layers the DMDA rule gives rank r of a (1,1,p) process
+grid, assembles the elements whose UPPER node layer it owns (the reference's
+DMDAGetElementsCorners/Sizes ownership), and owes the partial rows of node layer ks-1 to rank
+r-1: one point-to-point send per interface (RCCL on GPUs, gloo in the CPU tests) -- the data the
+reference moves inside MatAssemblyEnd's stash and DMLocalToGlobal(ADD_VALUES).
+"""
+import torch
+import torch.distributed as dist
+
+
+def slab_ranges(nlayers, nranks):
+    """PETSc DMDA split of node layers: rank r gets P/p + (P%p > r)."""
+    out, s = [], 0
+    for r in range(nranks):
+        n = nlayers // nranks + (1 if nlayers % nranks > r else 0)
+        out.append((s, s + n))
+        s += n
+    return out
+
+
+def element_range(ks, ke):
+    """Element layers assembled by the owner of node layers [ks,ke)."""
+    return max(ks - 1, 0), ke - 1
+
+
+def _span(i, M):
+    return 1 if M == 1 else 3 - (i == 0) - (i == M - 1)
+
+
+def _tot(M):
+    return 1 if M == 1 else 3 * M - 2
+
+
+def _pre(i, M):
+    if M == 1:
+        return i
+    if i <= 0:
+        return 0
+    if i >= M:
+        return 3 * M - 2
+    return 3 * i - 1
+
+
+def layer_nnz(nsd, dof, M, N, P, l0, l1):
+    """Stored entries of the rows of node layers [l0,l1) of the slowest direction (closed form of
+    the DMDA BOX-stencil pattern; mirrors femasm_device.h)."""
+    if nsd == 3:
+        return dof * dof * (_pre(l1, P) - _pre(l0, P)) * _tot(N) * _tot(M)
+    return dof * dof * (_pre(l1, N) - _pre(l0, N)) * _tot(M)
+
+
+def interface_counts(nsd, dof, M, N, P, ks, ke):
+    """(send_count, recv_count) in doubles: CSR rows of one node layer + its b slice."""
+    SL = P if nsd == 3 else N
+    plane = M * N if nsd == 3 else M
+    send = layer_nnz(nsd, dof, M, N, P, ks - 1, ks) + plane * dof if ks > 0 else 0
+    recv = layer_nnz(nsd, dof, M, N, P, ke - 1, ke) + plane * dof if ke < SL else 0
+    return send, recv
+
+
+def exchange_interface(send, recv, rank, world):
+    """rank r sends its `send` tensor to r-1 and receives `recv` from r+1.  No collective."""
+    if world == 1:
+        return
+    ops = []
+    if rank > 0 and send is not None and send.numel() > 0:
+        ops.append(dist.P2POp(dist.isend, send, rank - 1))
+    if rank < world - 1 and recv is not None and recv.numel() > 0:
+        ops.append(dist.P2POp(dist.irecv, recv, rank + 1))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()

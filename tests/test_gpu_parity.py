@@ -1,0 +1,274 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same
+inputs.  Tolerance: north_star's 1e-12 relative Frobenius norm on K (and on b); the kernels actually land
+near 1e-15, asserted at 1e-13 so a regression shows.  Integer outputs (pattern, scatter map, compressed
+pattern) are bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-13
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def env(O):
+    import torch
+    from petsc_amd import femasm as F
+    from petsc_amd import slab, synth
+    assert torch.cuda.is_available()
+    F.load()
+    return dict(torch=torch, F=F, O=O, slab=slab, synth=synth, dev=torch.device("cuda:0"))
+
+
+def make_case(env, kind, dims, perturb=True, vary_material=False):
+    """Inputs + oracle system for one problem kind."""
+    O, F = env["O"], env["F"]
+    rng = np.random.default_rng(7)
+    if kind == "p3":
+        M, N, P = dims
+        coords = O.uniform_coords(3, M, N, P)
+        if perturb:
+            coords = O.perturb_coords(coords, 3, M, N, P)
+        rp, ci = O.pattern(3, 1, M, N, P)
+        K, b = O.assemble_poisson3d(M, N, P, coords, rp, ci)
+        return dict(problem=F.POISSON3D_Q1, dims=(M, N, P), coords=coords, props=None, stride=0,
+                    bc=F.BC_POISSON_INLOOP, rp=rp, ci=ci, K=K, b=b)
+    if kind == "e2":
+        M, N = dims
+        coords = O.uniform_coords(2, M, N)
+        if perturb:
+            coords = O.perturb_coords(coords, 2, M, N)
+        rp, ci = O.pattern(2, 2, M, N)
+        props = O.props_e2(M - 1, N - 1, coords).reshape(-1, 24)
+        props[:, 16:24] = rng.uniform(-1, 1, size=(props.shape[0], 8))  # body force: exercise the RHS
+        if vary_material:
+            props[:, 8:12] = rng.uniform(0.5, 2.0, size=(props.shape[0], 4))
+            props[:, 12:16] = rng.uniform(0.1, 0.4, size=(props.shape[0], 4))
+        props = props.reshape(-1)
+        K, b = O.assemble_elastic2d(M, N, coords, props, rp, ci)
+        O.bc_e2(M, N, rp, ci, K, b)
+        return dict(problem=F.PLANE_STRAIN2D_Q1, dims=(M, N, 1), coords=coords, props=props, stride=24,
+                    bc=F.BC_E2_COMPRESSION, rp=rp, ci=ci, K=K, b=b)
+    M, N, P = dims
+    coords = O.uniform_coords(3, M, N, P)
+    if perturb:
+        coords = O.perturb_coords(coords, 3, M, N, P)
+    rp, ci = O.pattern(3, 3, M, N, P)
+    props = O.props_s3(M - 1, N - 1, P - 1, coords).reshape(-1, 400)
+    if vary_material:
+        props[:, 96:104] = rng.uniform(50, 150, size=(props.shape[0], 8))
+        props[:, 104:112] = rng.uniform(0.1, 0.4, size=(props.shape[0], 8))
+        props[:, 112:136] = rng.uniform(50, 150, size=(props.shape[0], 24))
+        props[:, 136:160] = rng.uniform(0.1, 0.4, size=(props.shape[0], 24))
+        props[:, 184:400] = rng.uniform(-1, 1, size=(props.shape[0], 216))
+    props = props.reshape(-1)
+    K, b = O.assemble_elastic3d(M, N, P, coords, props, rp, ci)
+    O.bc_s3(M, N, P, coords, rp, ci, K, b)
+    return dict(problem=F.ELASTIC3D_Q1, dims=(M, N, P), coords=coords, props=props, stride=400,
+                bc=F.BC_S3_ALLFACES_EXACT, rp=rp, ci=ci, K=K, b=b)
+
+
+def gpu_assemble(env, case, host_buffers=False, bc=None):
+    torch, F, dev = env["torch"], env["F"], env["dev"]
+    M, N, P = case["dims"]
+    to = (lambda a: a) if host_buffers else (lambda a: torch.from_numpy(a).to(dev))
+    plan = F.Plan(case["problem"], M, N, P, coords=to(case["coords"]))
+    if host_buffers:
+        vals, b = np.full(plan.nnz, np.nan), np.full(plan.nrows, np.nan)
+    else:
+        vals = torch.full((plan.nnz,), float("nan"), dtype=torch.float64, device=dev)
+        b = torch.full((plan.nrows,), float("nan"), dtype=torch.float64, device=dev)
+    mat = None if case["props"] is None else to(case["props"])
+    plan.assemble_system(vals, b, material=mat, stride=case["stride"], bc=case["bc"] if bc is None else bc)
+    if not host_buffers:
+        vals, b = vals.cpu().numpy(), b.cpu().numpy()
+    return plan, vals, b
+
+
+CASES = [
+    ("p3", (5, 5, 5)), ("p3", (9, 6, 7)), ("p3", (2, 2, 2)), ("p3", (3, 2, 10)), ("p3", (17, 13, 6)),
+    ("e2", (2, 2)), ("e2", (9, 7)), ("e2", (40, 21)), ("e2", (17, 5)), ("e2", (3, 50)),
+    ("s3", (2, 2, 2)), ("s3", (4, 4, 4)), ("s3", (8, 6, 7)), ("s3", (5, 9, 3)), ("s3", (13, 4, 6)),
+]
+
+
+@pytest.mark.parametrize("kind,dims", CASES)
+@pytest.mark.parametrize("perturb", [False, True])
+def test_system_matches_oracle(env, kind, dims, perturb):
+    case = make_case(env, kind, dims, perturb=perturb)
+    plan, vals, b = gpu_assemble(env, case)
+    rp, ci = plan.pattern()
+    assert np.array_equal(rp, case["rp"]) and np.array_equal(ci, case["ci"])  # bit-exact pattern (A12)
+    assert not np.isnan(vals).any() and not np.isnan(b).any()                  # every slot written
+    assert rel(vals, case["K"]) <= TOL
+    assert rel(b, case["b"]) <= TOL
+    plan.close()
+
+
+@pytest.mark.parametrize("kind,dims", [("e2", (12, 9)), ("s3", (6, 5, 7))])
+def test_per_gauss_point_material_and_loads(env, kind, dims):
+    case = make_case(env, kind, dims, vary_material=True)
+    plan, vals, b = gpu_assemble(env, case)
+    assert rel(vals, case["K"]) <= TOL and rel(b, case["b"]) <= TOL
+    plan.close()
+
+
+@pytest.mark.parametrize("kind,dims", [("p3", (6, 5, 4)), ("e2", (10, 6)), ("s3", (5, 4, 4))])
+def test_host_pointers_are_staged(env, kind, dims):
+    """The drivers hand in MatSeqAIJGetArray / VecGetArray host pointers."""
+    case = make_case(env, kind, dims)
+    plan, vals, b = gpu_assemble(env, case, host_buffers=True)
+    assert rel(vals, case["K"]) <= TOL and rel(b, case["b"]) <= TOL
+    plan.close()
+
+
+def test_uniform_material_equals_constant_aos(env):
+    torch, F, dev, O = env["torch"], env["F"], env["dev"], env["O"]
+    case = make_case(env, "s3", (6, 6, 5))
+    M, N, P = case["dims"]
+    plan = F.Plan(F.ELASTIC3D_Q1, M, N, P, coords=torch.from_numpy(case["coords"]).to(dev))
+    vals = torch.empty(plan.nnz, dtype=torch.float64, device=dev)
+    plan.assemble_system(vals, None, material=None, E=90.0, nu=0.28, bc=F.BC_S3_ALLFACES_EXACT)
+    assert rel(vals.cpu().numpy(), case["K"]) <= TOL
+    plan.close()
+
+
+def test_no_bc_gives_the_raw_operator(env):
+    O, F = env["O"], env["F"]
+    M, N, P = 5, 4, 6
+    coords = O.perturb_coords(O.uniform_coords(3, M, N, P), 3, M, N, P)
+    props = O.props_s3(M - 1, N - 1, P - 1, coords)
+    rp, ci = O.pattern(3, 3, M, N, P)
+    K, b = O.assemble_elastic3d(M, N, P, coords, props, rp, ci)
+    case = dict(problem=F.ELASTIC3D_Q1, dims=(M, N, P), coords=coords, props=props, stride=400, bc=F.BC_NONE)
+    plan, vals, bb = gpu_assemble(env, case)
+    assert rel(vals, K) <= TOL and rel(bb, b) <= TOL
+    plan.close()
+
+
+@pytest.mark.parametrize("kind,dims", [("p3", (4, 3, 5)), ("e2", (6, 4)), ("s3", (3, 4, 3))])
+def test_scatter_map_is_the_reference_index_map(env, kind, dims):
+    """A13: position of every (element, local row, local col) = where MatSetValuesStencil would add,
+    found here by searching the sorted CSR row."""
+    case = make_case(env, kind, dims, perturb=False)
+    plan, _, _ = gpu_assemble(env, case)
+    smap = plan.scatter_map()
+    M, N, P = case["dims"]
+    nsd, dof = plan.nsd, plan.dof
+    rp, ci = case["rp"], case["ci"]
+    hd = [(0, 0, 0), (0, 1, 0), (1, 1, 0), (1, 0, 0), (0, 0, 1), (0, 1, 1), (1, 1, 1), (1, 0, 1)]
+    qd = [(0, 0, 0), (0, 1, 0), (1, 1, 0), (1, 0, 0)]
+    offs = hd if nsd == 3 else qd
+    e = 0
+    for ek in range(max(P - 1, 1)):
+        for ej in range(N - 1):
+            for ei in range(M - 1):
+                eq = [dof * ((ei + o[0]) + M * ((ej + o[1]) + N * (ek + o[2]))) + c for o in offs for c in range(dof)]
+                for r, row in enumerate(eq):
+                    cols = ci[rp[row]:rp[row + 1]]
+                    want = rp[row] + np.searchsorted(cols, eq)
+                    assert np.array_equal(smap[e, r], want)
+                e += 1
+    assert e == plan.nel
+    plan.close()
+
+
+@pytest.mark.parametrize("kind,dims", [("e2", (7, 5)), ("s3", (4, 3, 4))])
+def test_compressed_bc_rows_match_petsc_matzerorows_default(env, kind, dims):
+    O = env["O"]
+    case = make_case(env, kind, dims)
+    plan, vals, _ = gpu_assemble(env, case)
+    M, N, P = case["dims"]
+    flags = O.bc_flags("e2" if kind == "e2" else "s3", M, N, P)
+    rp2, ci2, v2 = O.compress_zeroed_rows(flags, case["rp"], case["ci"], case["K"])
+    grp, gci, gv = plan.compress_bc_rows(vals, case["bc"])
+    assert np.array_equal(grp, rp2) and np.array_equal(gci, ci2)
+    assert rel(gv, v2) <= TOL
+    plan.close()
+
+
+@pytest.mark.parametrize("kind,dims,nslab", [("p3", (5, 4, 9), 3), ("e2", (9, 11), 2), ("s3", (4, 5, 8), 2),
+                                             ("s3", (3, 3, 7), 4)])
+def test_slabs_plus_interface_exchange_equal_the_global_system(env, kind, dims, nslab):
+    """Multi-GPU path on one device: one plan per slab, the send buffer of slab r+1 handed to slab r
+    (what RCCL does in bench.py), then femasm_interface_apply."""
+    torch, F, dev, slab = env["torch"], env["F"], env["dev"], env["slab"]
+    case = make_case(env, kind, dims, vary_material=(kind != "p3"))
+    M, N, P = case["dims"]
+    nsd = 2 if kind == "e2" else 3
+    SL = P if nsd == 3 else N
+    plane_n = (M * N if nsd == 3 else M)
+    plane_e = ((M - 1) * (N - 1) if nsd == 3 else (M - 1))
+    ranges = slab.slab_ranges(SL, nslab)
+    plans, outs, bufs = [], [], []
+    for (ks, ke) in ranges:
+        cks, cke = max(ks - 1, 0), min(ke + 1, SL)
+        els, ele = slab.element_range(ks, ke)
+        co = torch.from_numpy(case["coords"].reshape(SL, -1)[cks:cke].reshape(-1).copy()).to(dev)
+        plan = F.Plan(case["problem"], M, N, P, coords=co, ks=ks, ke=ke, cks=cks, cke=cke)
+        mat = None
+        if case["props"] is not None:
+            mat = torch.from_numpy(case["props"].reshape(-1, plane_e * case["stride"])[els:ele].reshape(-1).copy()).to(dev)
+        vals = torch.full((plan.nnz,), float("nan"), dtype=torch.float64, device=dev)
+        b = torch.full((plan.nrows,), float("nan"), dtype=torch.float64, device=dev)
+        (sp, sc), (rp_, rc) = plan.interface_buffers()
+        assert (sc, rc) == slab.interface_counts(nsd, plan.dof, M, N, P, ks, ke)
+        send = torch.full((max(sc, 1),), float("nan"), dtype=torch.float64, device=dev)
+        recv = torch.full((max(rc, 1),), float("nan"), dtype=torch.float64, device=dev)
+        plan.interface_set_buffers(send if sc else None, recv if rc else None)
+        plan.assemble_system(vals, b, material=mat, stride=case["stride"], bc=case["bc"], e_ks=els)
+        plans.append(plan); outs.append((vals, b)); bufs.append((send, recv, sc, rc))
+    for r in range(nslab - 1):
+        assert bufs[r][3] == bufs[r + 1][2]
+        bufs[r][1][:bufs[r][3]].copy_(bufs[r + 1][0][:bufs[r + 1][2]])  # "RCCL": slab r+1 -> slab r
+    for r in range(nslab):
+        plans[r].interface_apply(outs[r][0], outs[r][1], bc=case["bc"])
+    K = np.concatenate([o[0].cpu().numpy() for o in outs])
+    b = np.concatenate([o[1].cpu().numpy() for o in outs])
+    assert not np.isnan(K).any() and not np.isnan(b).any()
+    assert rel(K, case["K"]) <= TOL and rel(b, case["b"]) <= TOL
+    # per-slab pattern = global pattern rows, local rowptr, global column ids
+    off = 0
+    for r, (ks, ke) in enumerate(ranges):
+        rp, ci = plans[r].pattern()
+        lo, hi = plane_n * plans[r].dof * ks, plane_n * plans[r].dof * ke
+        assert np.array_equal(rp, case["rp"][lo:hi + 1] - case["rp"][lo])
+        assert np.array_equal(ci, case["ci"][case["rp"][lo]:case["rp"][hi]])
+        plans[r].close()
+
+
+def test_results_are_bitwise_reproducible(env):
+    case = make_case(env, "s3", (9, 8, 7))
+    p1, v1, b1 = gpu_assemble(env, case)
+    p2, v2, b2 = gpu_assemble(env, case)
+    assert np.array_equal(v1, v2) and np.array_equal(b1, b2)
+    p1.close(); p2.close()
+
+
+def test_inverted_element_is_reported(env):
+    torch, F, dev, O = env["torch"], env["F"], env["dev"], env["O"]
+    M = 4
+    coords = O.uniform_coords(3, M, M, M).reshape(-1, 3)
+    coords[21] = coords[21] + np.array([2.0, 0.0, 0.0])  # push an interior node through its neighbours
+    plan = F.Plan(F.POISSON3D_Q1, M, M, M, coords=torch.from_numpy(coords.reshape(-1)).to(dev))
+    vals = torch.empty(plan.nnz, dtype=torch.float64, device=dev)
+    with pytest.raises(F.FemasmError) as ei:
+        plan.assemble_system(vals, None, bc=F.BC_POISSON_INLOOP)
+    assert ei.value.code == 3 and "det(J)" in str(ei.value)
+    plan.close()
+
+
+def test_mismatched_bc_kind_is_rejected(env):
+    torch, F, dev, O = env["torch"], env["F"], env["dev"], env["O"]
+    plan = F.Plan(F.POISSON3D_Q1, 3, 3, 3, coords=torch.from_numpy(O.uniform_coords(3, 3, 3, 3)).to(dev))
+    vals = torch.empty(plan.nnz, dtype=torch.float64, device=dev)
+    with pytest.raises(F.FemasmError) as ei:
+        plan.assemble_system(vals, None, bc=F.BC_S3_ALLFACES_EXACT)
+    assert ei.value.code == 1
+    plan.close()
