@@ -232,8 +232,10 @@ int femasm_plan_create(const femasm_mesh *mesh, const femasm_quad *quad, int dev
     }                                                                                                \
   } while (0)
 
-  PCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
-  p->own_stream = true;
+  // Default: the legacy null stream, which orders with whatever the caller (PETSc, torch) queued on
+  // it or on any blocking stream.  femasm_plan_set_stream() moves the plan to a stream of the caller.
+  p->stream = nullptr;
+  p->own_stream = false;
   for (auto &e : p->ev) PCHK(hipEventCreate(&e));
 
   // coordinates
@@ -292,7 +294,6 @@ int femasm_plan_set_stream(femasm_plan *p, void *stream) {
   if (!p) return fail(FEMASM_ERR_ARG, "null plan");
   HIPCHK(hipSetDevice(p->device));
   HIPCHK(hipStreamSynchronize(p->stream));
-  if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
   p->stream = (hipStream_t)stream;
   p->own_stream = false;
   return FEMASM_OK;
