@@ -6,6 +6,7 @@
 // entry point needs a HIP device and fails loudly without one.
 #include "../../include/femasm.h"
 #include "femasm_kernels.h"
+#include "femasm_sweep.h"
 
 #include <hipcub/hipcub.hpp>
 
@@ -104,34 +105,86 @@ int64_t layer_nnz(const Slab &s, int64_t l0, int64_t l1) {
   return (int64_t)s.dof * s.dof * (b - a);
 }
 
+struct Box { int64_t x0, x1, y0, y1, s0, s1; };
+
 template <int KIND>
-int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, int64_t s0, int64_t s1, int iface) {
+KArgs make_kargs(femasm_plan *p, const femasm_material *mat, int bc, double *out, const Box &b, int64_t base_s0,
+                 int iface) {
   using T = Traits<KIND>;
-  if (s1 <= s0) return 0;
   KArgs a{};
   a.coords = p->coords;
   a.gp = (mat && mat->layout == FEMASM_MAT_AOS) ? (p->stage_gp ? p->stage_gp : mat->gp) : nullptr;
   a.out = out;
   a.bad = p->bad;
-  a.base_off = (T::NSD == 3) ? row_start(p->s, 0, 0, s0, 0) : row_start(p->s, 0, s0, 0, 0);
+  a.base_off = (T::NSD == 3) ? row_start(p->s, 0, 0, base_s0, 0) : row_start(p->s, 0, base_s0, 0, 0);
   a.cke = p->cke;
-  a.s0 = s0;
-  a.s1 = s1;
+  a.s0 = b.s0; a.s1 = b.s1;
+  a.x0 = b.x0; a.x1 = b.x1; a.y0 = b.y0; a.y1 = b.y1;
   a.E = mat ? mat->E : 0.0;
   a.nu = mat ? mat->nu : 0.0;
   a.mat_layout = mat ? mat->layout : FEMASM_MAT_UNIFORM;
   a.mat_stride = mat ? mat->stride : 0;
   a.bc = bc;
   a.iface = iface;
-  const int64_t M = p->s.dim[0], N = p->s.dim[1];
-  const int64_t nbx = (M + T::BX - 1) / T::BX;
-  int64_t nb;
-  if (T::NSD == 3) nb = nbx * ((N + T::BY - 1) / T::BY) * ((s1 - s0 + T::BZ - 1) / T::BZ);
-  else             nb = nbx * ((s1 - s0 + T::BY - 1) / T::BY);
-  if (nb > 0x7fffffffLL) return fail(FEMASM_ERR_ARG, "mesh too large for one launch (%lld bricks)", (long long)nb);
-  hipLaunchKernelGGL(k_assemble_rows<KIND>, dim3((unsigned)nb), dim3(256), 0, p->stream, p->s, a);
+  return a;
+}
+
+// general (any stencil, any BC) brick kernel over a node box
+template <int KIND>
+int launch_brick(femasm_plan *p, const femasm_material *mat, int bc, double *out, const Box &b, int64_t base_s0,
+                 int iface) {
+  using T = Traits<KIND>;
+  if (b.s1 <= b.s0 || b.x1 <= b.x0 || (T::NSD == 3 && b.y1 <= b.y0)) return 0;
+  const KArgs a = make_kargs<KIND>(p, mat, bc, out, b, base_s0, iface);
+  dim3 grid;
+  const unsigned nbx = (unsigned)((b.x1 - b.x0 + T::BX - 1) / T::BX);
+  if (T::NSD == 3) grid = dim3(nbx, (unsigned)((b.y1 - b.y0 + T::BY - 1) / T::BY), (unsigned)((b.s1 - b.s0 + T::BZ - 1) / T::BZ));
+  else             grid = dim3(nbx, (unsigned)((b.s1 - b.s0 + T::BY - 1) / T::BY), 1);
+  if (grid.y > 65535u || grid.z > 65535u) return fail(FEMASM_ERR_ARG, "mesh too large for one launch");
+  hipLaunchKernelGGL(k_assemble_rows<KIND>, grid, dim3(256), 0, p->stream, p->s, a);
   HIPCHK(hipGetLastError());
   return 0;
+}
+
+// K of node layers [s0,s1) of the slab direction into `out` (whose first row is the first row of layer s0)
+template <int KIND>
+int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, int64_t s0, int64_t s1, int iface) {
+  using T = Traits<KIND>;
+  if (s1 <= s0) return 0;
+  const int64_t M = p->s.dim[0], N = p->s.dim[1], P = p->s.dim[2];
+  if constexpr (T::NSD == 2) {
+    return launch_brick<KIND>(p, mat, bc, out, Box{0, M, 0, 1, s0, s1}, s0, iface);
+  } else {
+    const bool shell_is_bc = (bc == FEMASM_BC_POISSON_INLOOP || bc == FEMASM_BC_S3_ALLFACES_EXACT);
+    if (shell_is_bc) {  // Dirichlet rows of the boundary shell
+      const KArgs a = make_kargs<KIND>(p, mat, bc, out, Box{0, M, 0, N, s0, s1}, s0, iface);
+      hipLaunchKernelGGL(k_bc_rows, dim3(nblk(M), (unsigned)N, (unsigned)(s1 - s0)), dim3(256), 0, p->stream, p->s, a);
+      HIPCHK(hipGetLastError());
+    }
+    // interior nodes (full 27-neighbour stencil): z-sweep kernel
+    const int64_t z0 = s0 > 1 ? s0 : 1, z1 = s1 < P - 1 ? s1 : P - 1;
+    if (M > 2 && N > 2 && z1 > z0) {
+      const Box b{1, M - 1, 1, N - 1, z0, z1};
+      const KArgs a = make_kargs<KIND>(p, mat, bc, out, b, s0, iface);
+      dim3 grid((unsigned)((b.x1 - b.x0 + SW_TX - 1) / SW_TX), (unsigned)((b.y1 - b.y0 + SW_TY - 1) / SW_TY),
+                (unsigned)((z1 - z0 + SW_ZC - 1) / SW_ZC));
+      hipLaunchKernelGGL(k_assemble_sweep<KIND>, grid, dim3(256), 0, p->stream, p->s, a);
+      HIPCHK(hipGetLastError());
+    }
+    if (!shell_is_bc) {  // boundary rows that are real equations: general brick kernel on the six faces
+      int rc = 0;
+      if (s0 == 0) rc = launch_brick<KIND>(p, mat, bc, out, Box{0, M, 0, N, 0, 1}, s0, iface);
+      if (!rc && s1 == P && P - 1 >= s0 && P > 1) rc = launch_brick<KIND>(p, mat, bc, out, Box{0, M, 0, N, P - 1, P}, s0, iface);
+      if (!rc && z1 > z0) {
+        rc = launch_brick<KIND>(p, mat, bc, out, Box{0, M, 0, 1, z0, z1}, s0, iface);
+        if (!rc && N > 1) rc = launch_brick<KIND>(p, mat, bc, out, Box{0, M, N - 1, N, z0, z1}, s0, iface);
+        if (!rc && N > 2) rc = launch_brick<KIND>(p, mat, bc, out, Box{0, 1, 1, N - 1, z0, z1}, s0, iface);
+        if (!rc && N > 2 && M > 1) rc = launch_brick<KIND>(p, mat, bc, out, Box{M - 1, M, 1, N - 1, z0, z1}, s0, iface);
+      }
+      if (rc) return rc;
+    }
+    return 0;
+  }
 }
 
 template <int KIND>
@@ -153,11 +206,17 @@ int launch_rhs(femasm_plan *p, const femasm_material *mat, int bc, double *out, 
   a.bc = bc;
   a.iface = iface;
   if (do_elem && p->nel > 0) {
-    hipLaunchKernelGGL(k_rhs_elem<KIND>, dim3(nblk(p->nel)), dim3(256), 0, p->stream, p->s, a);
+    if (KIND == KIND_ELASTIC)
+      hipLaunchKernelGGL(k_rhs_elem_elastic_coop,
+                         dim3(nblk(p->s.dim[0] - 1, 8), (unsigned)(p->s.dim[1] - 1), (unsigned)(p->s.ele - p->s.els)),
+                         dim3(256), 0, p->stream, p->s, a);
+    else
+      hipLaunchKernelGGL(k_rhs_elem<KIND>, dim3(nblk(p->nel)), dim3(256), 0, p->stream, p->s, a);
     HIPCHK(hipGetLastError());
   }
-  const int64_t nn = (T::NSD == 3) ? p->s.dim[0] * p->s.dim[1] * (s1 - s0) : p->s.dim[0] * (s1 - s0);
-  hipLaunchKernelGGL(k_rhs_gather<KIND>, dim3(nblk(nn)), dim3(256), 0, p->stream, p->s, a);
+  const dim3 ggrid = (T::NSD == 3) ? dim3(nblk(p->s.dim[0]), (unsigned)p->s.dim[1], (unsigned)(s1 - s0))
+                                   : dim3(nblk(p->s.dim[0]), (unsigned)(s1 - s0), 1);
+  hipLaunchKernelGGL(k_rhs_gather<KIND>, ggrid, dim3(256), 0, p->stream, p->s, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -188,6 +247,7 @@ int femasm_plan_create(const femasm_mesh *mesh, const femasm_quad *quad, int dev
     return fail(FEMASM_ERR_ARG, "coords layers [%lld,%lld) must cover [%lld,%lld)", (long long)mesh->cks,
                 (long long)mesh->cke, (long long)need_lo, (long long)mesh->ke);
   if (!mesh->coords) return fail(FEMASM_ERR_ARG, "coords is null");
+  if (N > 65535 || P > 65535) return fail(FEMASM_ERR_ARG, "at most 65535 nodes in the y and z directions (grid limits)");
   if ((double)dof * M * N * P > 2.0e9) return fail(FEMASM_ERR_ARG, "global row count exceeds int32 column ids");
 
   int ndev = 0;

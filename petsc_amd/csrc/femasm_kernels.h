@@ -18,6 +18,9 @@
 //    reference's element order (k->j->i).
 #pragma once
 #include "femasm_device.h"
+#ifndef FEMASM_EXP
+#define FEMASM_EXP 0
+#endif
 
 namespace femasm {
 
@@ -115,6 +118,7 @@ struct KArgs {
   int64_t base_off;       // row_start of the first processed row (subtracted)
   int64_t cke;            // one past the last coords layer
   int64_t s0, s1;         // processed node layers of the slowest direction
+  int64_t x0, x1, y0, y1; // processed node box in the fast directions (y unused in 2-D)
   double E, nu;           // uniform material
   int32_t mat_layout, mat_stride;
   int32_t bc;             // BC_* kind
@@ -281,19 +285,16 @@ __global__ __launch_bounds__(256, 2) void k_assemble_rows(const Slab s, const KA
 
   // ---- brick -> global ----------------------------------------------------
   const int64_t M = s.dim[0], N = s.dim[1], P = s.dim[2];
-  const int64_t nbx = (M + BX - 1) / BX;
-  const int64_t bid = blockIdx.x;
-  int64_t g0x, g0y, g0z;  // global index of the brick's first node
+  int64_t g0x, g0y, g0z;  // global index of the brick's first node; grid = bricks per direction
   int lx, ly, lz;
   if constexpr (NSD == 3) {
-    const int64_t nby = (N + BY - 1) / BY;
-    g0x = (bid % nbx) * BX;
-    g0y = ((bid / nbx) % nby) * BY;
-    g0z = a.s0 + (bid / (nbx * nby)) * BZ;
+    g0x = a.x0 + (int64_t)blockIdx.x * BX;
+    g0y = a.y0 + (int64_t)blockIdx.y * BY;
+    g0z = a.s0 + (int64_t)blockIdx.z * BZ;
     lx = lane & 3; ly = (lane >> 2) & 3; lz = lane >> 4;
   } else {
-    g0x = (bid % nbx) * BX;
-    g0y = a.s0 + (bid / nbx) * BY;
+    g0x = a.x0 + (int64_t)blockIdx.x * BX;
+    g0y = a.s0 + (int64_t)blockIdx.y * BY;
     g0z = 0;
     lx = lane & 15; ly = lane >> 4; lz = 0;
   }
@@ -457,8 +458,12 @@ __global__ __launch_bounds__(256, 2) void k_assemble_rows(const Slab s, const KA
   geometry(0, sh_rec);
   __syncthreads();
   for (int p = 0; p < NGP; p++) {
+#if FEMASM_EXP != 3
     if (p + 1 < NGP) geometry(p + 1, sh_rec + ((p + 1) & 1) * (NE * REC));
+#endif
+#if FEMASM_EXP != 2
     contract(sh_rec + (p & 1) * (NE * REC));
+#endif
     __syncthreads();
   }
 
@@ -480,8 +485,8 @@ __global__ __launch_bounds__(256, 2) void k_assemble_rows(const Slab s, const KA
   const int ds = oes + obs;  // -1, 0, +1 : neighbour layer in the slowest direction
   bool valid;
   int64_t sl, SL;            // index / extent of the slowest direction
-  if constexpr (NSD == 3) { valid = i < M && j < N && k < a.s1; sl = k; SL = P; }
-  else                    { valid = i < M && j < a.s1;          sl = j; SL = N; }
+  if constexpr (NSD == 3) { valid = i < a.x1 && j < a.y1 && k < a.s1; sl = k; SL = P; }
+  else                    { valid = i < a.x1 && j < a.s1;            sl = j; SL = N; }
   if (!valid || sl + ds < 0 || sl + ds > SL - 1) return;
 
   const bool isbc = is_bc_node(s, a.bc, i, j, k);
@@ -512,7 +517,11 @@ __global__ __launch_bounds__(256, 2) void k_assemble_rows(const Slab s, const KA
           for (int cc = 0; cc < DOF; cc++) {
             double v = acc[((dy + 1) * 3 + (dx + 1)) * DD + c * DOF + cc];
             if (isbc) v = (ds == 0 && dy == 0 && dx == 0 && cc == c) ? bcdiag : 0.0;
+#if FEMASM_EXP == 1
+            asm volatile("" :: "v"(v));
+#else
             row[DOF * idx + cc] = v;
+#endif
           }
         }
       }
@@ -657,6 +666,104 @@ __global__ __launch_bounds__(256) void k_rhs_elem(const Slab s, const RArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// RHS, pass 1 for S3/R3, cooperative form: 32 lanes per element, 8 elements per workgroup.
+// Lane q < 24 owns face Gauss point q (traction sigma.n * face Jacobian, S3:568-648), lane
+// q >= 24 owns volume Gauss point q-24 (w*detJ * f, S3:534-545); the 2.3 KB of per-element
+// AoS inputs are read as contiguous runs across lanes.  Then lane q < 24 = dof (node q/3,
+// component q%3) sums its 8 + 24 terms in Gauss-point order and writes Fe / Ge contiguously.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rhs_elem_elastic_coop(const Slab s, const RArgs a) {
+  // per element: AoS doubles [112,400) = E_B[24] nu_B[24] fx[8] fy[8] fz[8] gx[72] gy[72] gz[72]
+  __shared__ __attribute__((aligned(16))) double sh_in[8][288];
+  __shared__ double sh_xc[8][24];
+  __shared__ double sh_t[8][24][3];
+  __shared__ double sh_u[8][8][3];
+  __shared__ double sh_N[8][8];
+  __shared__ double sh_NF[24][8];
+  const int tid = threadIdx.x, el = tid >> 5, q = tid & 31;
+  // grid = (ceil(mx/8), my, element layers): no integer division on the hot path
+  const int64_t M = s.dim[0], N = s.dim[1];
+  const int64_t mx = M - 1, my = N - 1;
+  const int64_t ex = (int64_t)blockIdx.x * 8 + el, ey = blockIdx.y, ez = s.els + blockIdx.z;
+  const bool live = ex < mx;
+  const int64_t e = ex + mx * (ey + my * (int64_t)blockIdx.z);
+  const bool aos = a.mat_layout == 0;
+  if (tid < 64) sh_N[tid >> 3][tid & 7] = c_tab3.N[tid >> 3][tid & 7];
+  else sh_NF[(tid - 64) >> 3][tid & 7] = c_tab3.NF[(tid - 64) >> 3][tid & 7];
+  if (live) {
+    if (q < 24) {
+      const int n = q / 3, d = q % 3;
+      const int64_t node = (ex + HDI[n]) + M * ((ey + HDJ[n]) + N * (ez + HDK[n] - s.cks));
+      sh_xc[el][q] = a.coords[3 * node + d];
+    }
+    if (aos) {  // contiguous, 16 bytes per lane (the element block is 16-byte aligned for every stride in use)
+      const double *pr = a.gp + (ex + mx * (ey + my * (ez - s.mat_e_ks))) * a.mat_stride + 112;
+      if ((a.mat_stride & 1) == 0) {
+        const double2 *src = reinterpret_cast<const double2 *>(pr);
+        double2 *dst = reinterpret_cast<double2 *>(sh_in[el]);
+        for (int k = q; k < 144; k += 32) dst[k] = src[k];
+      } else {
+        for (int k = q; k < 288; k += 32) sh_in[el][k] = pr[k];
+      }
+    }
+  }
+  __syncthreads();
+  if (live) {
+    const double *xc = sh_xc[el];
+    const double *in = sh_in[el];
+    if (q < 24) {
+      double sn[3] = {0.0, 0.0, 0.0};
+      if (aos) {
+        const double dx = fabs(xc[0] - xc[9]), dy = fabs(xc[1] - xc[4]), dz = fabs(xc[2] - xc[14]);
+        const double *gx = in + 72, *gy = in + 144, *gz = in + 216;
+        const double pe = in[q], pn = in[24 + q];
+        const double factor = pe * (1 - pn) / ((1.0 + pn) * (1.0 - 2.0 * pn));
+        const double d11 = factor * 1.0, d12 = factor * (pn / (1 - pn)), d44 = factor * (0.5 * (1 - 2 * pn) / (1 - pn));
+        const double e0 = gx[3 * q], e1 = gy[3 * q + 1], e2 = gz[3 * q + 2];
+        const double e3 = gx[3 * q + 1] + gy[3 * q], e4 = gy[3 * q + 2] + gz[3 * q + 1], e5 = gx[3 * q + 2] + gz[3 * q];
+        const double z0 = d11 * e0 + d12 * e1 + d12 * e2;
+        const double z1 = d12 * e0 + d11 * e1 + d12 * e2;
+        const double z2 = d12 * e0 + d12 * e1 + d11 * e2;
+        const double z3 = d44 * e3, z4 = d44 * e4, z5 = d44 * e5;
+        const int axis = q >> 3;
+        const double side = ((q >> 2) & 1) ? -1.0 : 1.0;
+        double Jp;
+        if (axis == 0)      { sn[0] = z0 * side; sn[1] = z3 * side; sn[2] = z5 * side; Jp = (0.5 * dy) * (0.5 * dz); }
+        else if (axis == 1) { sn[0] = z3 * side; sn[1] = z1 * side; sn[2] = z4 * side; Jp = (0.5 * dx) * (0.5 * dz); }
+        else                { sn[0] = z5 * side; sn[1] = z4 * side; sn[2] = z2 * side; Jp = (0.5 * dx) * (0.5 * dy); }
+        const double fac = 1.0 * Jp;
+#pragma unroll
+        for (int c = 0; c < 3; c++) sn[c] *= fac;
+      }
+#pragma unroll
+      for (int c = 0; c < 3; c++) sh_t[el][q][c] = sn[c];
+    } else {
+      const int p = q - 24;
+      double u[3] = {0.0, 0.0, 0.0};
+      if (aos) {
+        const double fac = 1.0 * det3_only(c_tab3.G[p], xc);
+        u[0] = fac * in[48 + p];
+        u[1] = fac * in[56 + p];
+        u[2] = fac * in[64 + p];
+      }
+#pragma unroll
+      for (int c = 0; c < 3; c++) sh_u[el][p][c] = u[c];
+    }
+  }
+  __syncthreads();
+  if (live && q < 24) {
+    const int n = q / 3, c = q % 3;
+    double fe = 0.0, ge = 0.0;
+#pragma unroll
+    for (int p = 0; p < 8; p++) fe += sh_N[p][n] * sh_u[el][p][c];
+#pragma unroll
+    for (int p = 0; p < 24; p++) ge += sh_NF[p][n] * sh_t[el][p][c];
+    a.elemF[e * 48 + q] = fe;
+    a.elemF[e * 48 + 24 + q] = ge;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // RHS, pass 2: one thread per node; contributions added in the reference's element
 // order (k -> j -> i), Fe before Ge (S3:787-788); then the Dirichlet value.
 // ---------------------------------------------------------------------------
@@ -666,12 +773,12 @@ __global__ __launch_bounds__(256) void k_rhs_gather(const Slab s, const RArgs a)
   constexpr int NSD = T::NSD, DOF = T::DOF, NFE = T::NFE;
   const int64_t M = s.dim[0], N = s.dim[1];
   const int64_t mx = M - 1, my = N - 1;
-  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t nn = (NSD == 3) ? M * N * (a.s1 - a.s0) : M * (a.s1 - a.s0);
-  if (q >= nn) return;
-  int64_t i = q % M, j, k;
-  if constexpr (NSD == 3) { j = (q / M) % N; k = a.s0 + q / (M * N); }
-  else                    { j = a.s0 + q / M; k = 0; }
+  // grid = (ceil(M/256), N or layers, layers or 1): no integer division
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M) return;
+  int64_t j, k, q;
+  if constexpr (NSD == 3) { j = blockIdx.y; k = a.s0 + blockIdx.z; q = i + M * (j + N * (int64_t)blockIdx.z); }
+  else                    { j = a.s0 + blockIdx.y; k = 0; q = i + M * (int64_t)blockIdx.y; }
 
   double b[DOF];
 #pragma unroll

@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libfemasm.so")
+LIB_PATH = os.environ.get("FEMASM_LIB", os.path.join(_HERE, "csrc", "libfemasm.so"))  # override: kernel experiments
 
 POISSON3D_Q1, PLANE_STRAIN2D_Q1, ELASTIC3D_Q1 = 0, 1, 2
 MAT_AOS, MAT_UNIFORM = 0, 1
