@@ -36,6 +36,12 @@ def parse():
     ap.add_argument("--strong", action="store_true", help="fixed global mesh split over N slabs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--k-only", action="store_true", help="time K assembly only (no b)")
+    ap.add_argument("--fast-level", type=int, default=2, choices=[0, 1, 2],
+                    help="stiffness kernel: 2 box / 1 affine / 0 general (falls back by itself when the mesh "
+                         "does not qualify)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse "
+                    "several ranks on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use GPU 0")
     return ap.parse_args()
 
 
@@ -94,11 +100,16 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the femasm engine has no CPU path")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     wl = args.workload
     if wl == "elastic3d":
@@ -138,6 +149,7 @@ def main():
 
     plan = F.Plan(kind, M, N, P, coords=coords, ks=ks, ke=ke, cks=cks, cke=cke, device=local_rank)
     plan.set_stream(torch.cuda.current_stream().cuda_stream)
+    plan.set_fast_path(args.fast_level)
     vals = torch.empty(plan.nnz, dtype=torch.float64, device=dev)
     b = None if args.k_only else torch.empty(plan.nrows, dtype=torch.float64, device=dev)
 
@@ -187,8 +199,16 @@ def main():
         ms_per_step = 1e3 * dt / args.steps
         k_avg_ms = sum(k_ms) / len(k_ms)
         achieved = st.bytes_K / (k_avg_ms * 1e-3) / 1e9
-        kernel = {"elastic3d": "k_assemble_rows<ELASTIC3D>", "poisson3d": "k_assemble_rows<POISSON3D>",
-                  "elastic2d": "k_assemble_rows<PLANE_STRAIN2D>"}[wl]
+        level = plan.fast_path()
+        if wl == "elastic2d":
+            kernel = "k_assemble_rows<PLANE_STRAIN2D>"
+        else:
+            kname = "ELASTIC3D" if wl == "elastic3d" else "POISSON3D"
+            if level == 0:
+                kernel = f"k_assemble_sweep<{kname}>"
+            else:
+                box = "true" if (level == 2 and wl == "elastic3d") else "false"
+                kernel = f"k_assemble_sweep_affine<{kname}, box={box}>"
         out = {
             "metric": "global assembly elements/sec + achieved HBM GB/s fraction",
             "value": nel_total / (dt / args.steps),
@@ -214,6 +234,7 @@ def main():
             },
             "roofline": {
                 "kernel": kernel,
+                "kernel_level": level,
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

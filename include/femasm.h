@@ -99,6 +99,18 @@ int femasm_plan_destroy(femasm_plan *plan);
 /* Launch everything on `stream` (a hipStream_t) instead of the plan's own stream. */
 int femasm_plan_set_stream(femasm_plan *plan, void *stream);
 
+/* No counterpart in the reference (an optimisation switch of this engine).  The 3-D kinds
+ * have a specialised stiffness kernel besides the general one:
+ *   level 2  elastic: axis-aligned box elements (what DMDASetUniformCoordinates P3:663 /
+ *            S3:1198 produces) with one (E,nu) per element; Poisson: as level 1
+ *   level 1  Poisson: affine elements (parallelepipeds); elastic: as level 0
+ *   level 0  general isoparametric elements, (E,nu) per Gauss point
+ * The specialised kernel tests its premise on every element it touches, exactly (bitwise-equal
+ * edge vectors and material); on any failure femasm_assemble_system reassembles K with the
+ * general kernel and the plan stays at level 0.  Default 2.  Results differ by rounding only. */
+int femasm_plan_set_fast_path(femasm_plan *plan, int level);
+int femasm_plan_get_fast_path(femasm_plan *plan, int *level);
+
 /* Sparsity pattern of the owned rows (A12): rowptr is local (starts at 0, int64 so
  * 256^3 elastic fits), colidx holds GLOBAL column ids (= PETSc natural numbering for
  * z-slab layouts).  Device pointers, borrowed until destroy. */

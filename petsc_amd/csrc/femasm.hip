@@ -77,7 +77,9 @@ struct femasm_plan {
   int64_t send_count = 0, recv_count = 0, send_nnz = 0, recv_nnz = 0;
   bool own_send = true, own_recv = true;
 
-  unsigned long long *bad = nullptr;
+  unsigned long long *bad = nullptr;   // [0] Gauss points with det(J) <= 0, [1] elements that failed the affine test
+  int fast_level = 2;                  // 3-D kinds: try the row-sweep kernel (include/femasm.h), 0 = general
+  bool used_fast = false;
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -166,9 +168,18 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
     if (M > 2 && N > 2 && z1 > z0) {
       const Box b{1, M - 1, 1, N - 1, z0, z1};
       const KArgs a = make_kargs<KIND>(p, mat, bc, out, b, s0, iface);
-      dim3 grid((unsigned)((b.x1 - b.x0 + SW_TX - 1) / SW_TX), (unsigned)((b.y1 - b.y0 + SW_TY - 1) / SW_TY),
-                (unsigned)((z1 - z0 + SW_ZC - 1) / SW_ZC));
-      hipLaunchKernelGGL(k_assemble_sweep<KIND>, grid, dim3(256), 0, p->stream, p->s, a);
+      const bool fast = (KIND == KIND_ELASTIC) ? (p->fast_level == 2) : (p->fast_level >= 1);
+      if (fast) {
+        constexpr int TX = RowSweep<KIND>::TX, TY = RowSweep<KIND>::TY;
+        dim3 grid((unsigned)((b.x1 - b.x0 + TX - 1) / TX), (unsigned)((b.y1 - b.y0 + TY - 1) / TY),
+                  (unsigned)((z1 - z0 + RS_ZC - 1) / RS_ZC));
+        hipLaunchKernelGGL(k_assemble_rowsweep<KIND>, grid, dim3(256), 0, p->stream, p->s, a);
+        p->used_fast = true;
+      } else {
+        dim3 grid((unsigned)((b.x1 - b.x0 + SW_TX - 1) / SW_TX), (unsigned)((b.y1 - b.y0 + SW_TY - 1) / SW_TY),
+                  (unsigned)((z1 - z0 + SW_ZC - 1) / SW_ZC));
+        hipLaunchKernelGGL(k_assemble_sweep<KIND>, grid, dim3(256), 0, p->stream, p->s, a);
+      }
       HIPCHK(hipGetLastError());
     }
     if (!shell_is_bc) {  // boundary rows that are real equations: general brick kernel on the six faces
@@ -311,8 +322,8 @@ int femasm_plan_create(const femasm_mesh *mesh, const femasm_quad *quad, int dev
 
   PCHK(hipMalloc(&p->rowptr, (p->nrows + 1) * sizeof(int64_t)));
   PCHK(hipMalloc(&p->colidx, (size_t)(p->nnz > 0 ? p->nnz : 1) * sizeof(int32_t)));
-  PCHK(hipMalloc(&p->bad, sizeof(unsigned long long)));
-  PCHK(hipMemsetAsync(p->bad, 0, sizeof(unsigned long long), p->stream));
+  PCHK(hipMalloc(&p->bad, 32 * sizeof(unsigned long long)));  // [0] bad detJ, [1] fast-path premise failures, rest: profiling builds
+  PCHK(hipMemsetAsync(p->bad, 0, 32 * sizeof(unsigned long long), p->stream));
   PCHK(hipMalloc(&p->elemF, (size_t)(p->nel > 0 ? p->nel : 1) * nfe * sizeof(double)));
 
   // interface buffers: rows of node layer ks-1 (owed to the rank below) and of ke-1 (owed to us)
@@ -339,6 +350,15 @@ int femasm_plan_destroy(femasm_plan *p) {
   if (!p) return FEMASM_OK;
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
+#if FEMASM_EXP == 3
+  {  // phase clocks of the row-sweep kernel (profiling build)
+    unsigned long long t[32];
+    if (p->bad && hipMemcpy(t, p->bad, sizeof t, hipMemcpyDeviceToHost) == hipSuccess) {
+      fprintf(stderr, "[femasm phases] row waves: n=%llu barrier %llu contract %llu stage %llu store %llu | record wave: n=%llu top %llu commit+load %llu build %llu handshakes %llu\n",
+              t[8], t[9], t[10], t[11], t[12], t[16], t[17], t[18], t[19], t[20]);
+    }
+  }
+#endif
   void *bufs[] = {p->coords_dev, p->rowptr, p->colidx, p->elemF, p->own_send ? p->send : nullptr,
                   p->own_recv ? p->recv : nullptr, p->bad, p->stage_vals, p->stage_b, p->stage_gp};
   for (void *b : bufs)
@@ -463,26 +483,32 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
   }
   ms_staging += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
-  HIPCHK(hipMemsetAsync(p->bad, 0, sizeof(unsigned long long), p->stream));
+  HIPCHK(hipMemsetAsync(p->bad, 0, 2 * sizeof(unsigned long long), p->stream));
 
   int rc = 0;
   // ---- K ----
-  if (stats) HIPCHK(hipEventRecord(p->ev[0], p->stream));
-  if (d_vals) {
+  auto run_K = [&]() -> int {
+    int r = 0;
     switch (p->kind) {
-      case KIND_POISSON: rc = launch_K<KIND_POISSON>(p, &mloc, bc, d_vals, s.ks, s.ke, 0); break;
-      case KIND_PLANE:   rc = launch_K<KIND_PLANE>(p, &mloc, bc, d_vals, s.ks, s.ke, 0); break;
-      case KIND_ELASTIC: rc = launch_K<KIND_ELASTIC>(p, &mloc, bc, d_vals, s.ks, s.ke, 0); break;
+      case KIND_POISSON: r = launch_K<KIND_POISSON>(p, &mloc, bc, d_vals, s.ks, s.ke, 0); break;
+      case KIND_PLANE:   r = launch_K<KIND_PLANE>(p, &mloc, bc, d_vals, s.ks, s.ke, 0); break;
+      case KIND_ELASTIC: r = launch_K<KIND_ELASTIC>(p, &mloc, bc, d_vals, s.ks, s.ke, 0); break;
     }
-    if (rc) return rc;
+    if (r) return r;
     if (s.ks > 0) {  // partial rows of node layer ks-1, owed to the rank below
       switch (p->kind) {
-        case KIND_POISSON: rc = launch_K<KIND_POISSON>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1); break;
-        case KIND_PLANE:   rc = launch_K<KIND_PLANE>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1); break;
-        case KIND_ELASTIC: rc = launch_K<KIND_ELASTIC>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1); break;
+        case KIND_POISSON: r = launch_K<KIND_POISSON>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1); break;
+        case KIND_PLANE:   r = launch_K<KIND_PLANE>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1); break;
+        case KIND_ELASTIC: r = launch_K<KIND_ELASTIC>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1); break;
       }
-      if (rc) return rc;
     }
+    return r;
+  };
+  p->used_fast = false;
+  if (stats) HIPCHK(hipEventRecord(p->ev[0], p->stream));
+  if (d_vals) {
+    rc = run_K();
+    if (rc) return rc;
   }
   if (stats) HIPCHK(hipEventRecord(p->ev[1], p->stream));
   // ---- b ----
@@ -508,17 +534,41 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
   t0 = std::chrono::steady_clock::now();
   if (vals_host) HIPCHK(hipMemcpyAsync(csr_values, d_vals, p->nnz * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   if (b_host) HIPCHK(hipMemcpyAsync(b, d_b, p->nrows * sizeof(double), hipMemcpyDeviceToHost, p->stream));
-  unsigned long long bad = 0;
-  HIPCHK(hipMemcpyAsync(&bad, p->bad, sizeof bad, hipMemcpyDeviceToHost, p->stream));
+  unsigned long long flags[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(flags, p->bad, sizeof flags, hipMemcpyDeviceToHost, p->stream));
   HIPCHK(hipStreamSynchronize(p->stream));
   if (vals_host || b_host)
     ms_staging += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+
+  double k_ms_redo = -1.0;
+  if (d_vals && p->used_fast && flags[1]) {
+    // The fast kernel verifies its own premise on every element (elastic: axis-aligned box,
+    // Poisson: parallelepiped; one (E,nu) per element).  Some element failed the test: the plan
+    // drops to the general kernel for good and K is assembled again, overwriting every value of
+    // the first attempt.
+    p->fast_level = 0;
+    p->used_fast = false;
+    HIPCHK(hipMemsetAsync(p->bad, 0, 2 * sizeof(unsigned long long), p->stream));
+    t0 = std::chrono::steady_clock::now();
+    rc = run_K();
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(flags, p->bad, sizeof flags, hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    k_ms_redo = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (vals_host) {
+      t0 = std::chrono::steady_clock::now();
+      HIPCHK(hipMemcpyAsync(csr_values, d_vals, p->nnz * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+      HIPCHK(hipStreamSynchronize(p->stream));
+      ms_staging += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+  }
+  const unsigned long long bad = flags[0];
 
   if (stats) {
     float k_ms = 0, r_ms = 0;
     HIPCHK(hipEventElapsedTime(&k_ms, p->ev[0], p->ev[1]));
     HIPCHK(hipEventElapsedTime(&r_ms, p->ev[1], p->ev[2]));
-    stats->ms_kernel_K = k_ms;
+    stats->ms_kernel_K = k_ms_redo >= 0.0 ? k_ms_redo : k_ms;
     stats->ms_kernel_rhs = r_ms;
     stats->ms_staging = ms_staging;
     stats->nel = p->nel;
@@ -533,6 +583,19 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
     stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   }
   if (bad) return fail(FEMASM_ERR_GEOMETRY, "%llu Gauss points with non-positive or NaN det(J)", bad);
+  return FEMASM_OK;
+}
+
+int femasm_plan_set_fast_path(femasm_plan *p, int level) {
+  if (!p) return fail(FEMASM_ERR_ARG, "null plan");
+  if (level < 0 || level > 2) return fail(FEMASM_ERR_ARG, "fast-path level %d not in 0..2", level);
+  p->fast_level = level;
+  return FEMASM_OK;
+}
+
+int femasm_plan_get_fast_path(femasm_plan *p, int *level) {
+  if (!p || !level) return fail(FEMASM_ERR_ARG, "null argument");
+  *level = p->fast_level;
   return FEMASM_OK;
 }
 

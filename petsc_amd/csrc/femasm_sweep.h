@@ -96,6 +96,63 @@ __device__ inline void sweep_contract(const double2 *__restrict__ recbuf, int my
     }
 }
 
+// transposed, coalesced store of one third (dz) of the rows of the wave's 64 nodes (node layer kn):
+// registers -> per-wave LDS area -> contiguous runs in HBM
+template <int KIND>
+__device__ inline void sweep_store_third(const Slab &s, const KArgs &a, const double *acc, double *stage, int lane,
+                                         int64_t i0, int64_t j0, int64_t kn, int dz, int nvx) {
+  constexpr int DOF = Traits<KIND>::DOF, DD = DOF * DOF, CH = 9 * DOF, NODESTRIDE = 27 * DD;
+  constexpr int NIT = (SW_TX * CH + 63) / 64;
+  int goff[NIT];  // position of staged value idx in the node-major CSR run of a tile row
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    const int idx = lane + 64 * it;
+    goff[it] = idx + (NODESTRIDE - CH) * (idx / CH);
+  }
+#if FEMASM_EXP == 2
+  {  // experiment: direct lane-wise stores, no LDS transposition
+    const int lx = lane & 15, r = lane >> 4, ly = ((r & 1) << 1) | (r >> 1);
+    if (lx < nvx && j0 + ly < a.y1) {
+      double *base = a.out + (row_start(s, i0 + lx, j0 + ly, kn, 0) - a.base_off) + (dz + 1) * CH;
+#pragma unroll
+      for (int c = 0; c < DOF; c++)
+#pragma unroll
+        for (int t = 0; t < 9; t++)
+#pragma unroll
+          for (int cc = 0; cc < DOF; cc++) base[c * (27 * DOF) + t * DOF + cc] = acc[t * DD + c * DOF + cc];
+    }
+    return;
+  }
+#endif
+#pragma unroll
+  for (int c = 0; c < DOF; c++) {
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+      for (int cc = 0; cc < DOF; cc++) stage[lane * CH + t * DOF + cc] = acc[t * DD + c * DOF + cc];
+    __builtin_amdgcn_wave_barrier();
+    for (int rr = 0; rr < 4; rr++) {
+      const int64_t jr = j0 + (((rr & 1) << 1) | (rr >> 1));
+      if (jr >= a.y1) continue;
+      double *base = a.out + (row_start(s, i0, jr, kn, 0) - a.base_off) + (int64_t)c * (27 * DOF) + (dz + 1) * CH;
+      const double *src = stage + rr * (SW_TX * CH);
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const int idx = lane + 64 * it;
+#if FEMASM_EXP == 1
+        if (idx < nvx * CH) asm volatile("" :: "v"(src[idx]));
+#else
+        if (idx < nvx * CH) base[goff[it]] = src[idx];
+#endif
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// general path: Jacobian, inverse and det per Gauss point (any hexahedron, per-Gauss-point material)
+// ---------------------------------------------------------------------------
 template <int KIND>
 __global__ __launch_bounds__(256, 2) void k_assemble_sweep(const Slab s, const KArgs a) {
   using T = Traits<KIND>;
@@ -107,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void k_assemble_sweep(const Slab s, const K
   static_assert(3 * 64 * CH * 8 <= 2 * NPAIR * SW_NS * 16, "staging aliases the record buffers");
 
   __shared__ double2 sh_rec[2 * NPAIR * SW_NS];   // 53 760 B
-  __shared__ double sh_x[3 * 108 * 3];             //  7 776 B: ring of three node layers (18x6 nodes each)
+  __shared__ double sh_x[2 * 108 * 3];            //  5 184 B: node layers L, L+1 of the 18x6 halo'd tile
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int lx = lane & 15, r = lane >> 4, ly = ((r & 1) << 1) | (r >> 1);
@@ -124,94 +181,47 @@ __global__ __launch_bounds__(256, 2) void k_assemble_sweep(const Slab s, const K
   const bool gthread = tid < SW_NS;
   const bool exy_ok = gthread && ex < SW_TX + 1 && gex >= 0 && gex < M - 1 && gey >= 0 && gey < N - 1;
 
-  // output: lane/iteration-invariant scatter offsets of the transposed store
-  int goff[NIT];
-#pragma unroll
-  for (int it = 0; it < NIT; it++) {
-    const int idx = lane + 64 * it;
-    goff[it] = idx + (NODESTRIDE - CH) * (idx / CH);
-  }
   const int nvx = (a.x1 - i0 < SW_TX) ? (int)(a.x1 - i0) : SW_TX;  // valid nodes of the tile in x
   // three waves write per step: A (wave 0), D (wave 3) and whichever of waves 1/2 finishes a middle third
   double *stage = reinterpret_cast<double *>(sh_rec) + ((w == 0) ? 0 : (w == 3 ? 1 : 2)) * (64 * CH);
 
   double acc[NACC];
 
-  // ---- coordinate ring: node layer zc0-1+m lives in ring slot m % 3.  Threads 128..235 (waves 2,3: the
-  //      waves without quadrature duty) own one node of the 18x6 halo'd tile each. ----
-  const int ctid = tid - 128;
-  const bool cthread = ctid >= 0 && ctid < 108;
-  int64_t cnode_xy = 0;
-  if (cthread) {
-    const int cy = ctid / 18, cx = ctid - 18 * cy;
-    int64_t gi = i0 - 1 + cx, gj = j0 - 1 + cy;
-    gi = gi < 0 ? 0 : (gi > M - 1 ? M - 1 : gi);
-    gj = gj < 0 ? 0 : (gj > N - 1 ? N - 1 : gj);
-    cnode_xy = gi + M * gj;
-  }
-  auto coord_ptr = [&](int64_t gk) {  // clamped: elements that would use a clamped layer are masked out
-    gk = gk < s.cks ? s.cks : (gk > a.cke - 1 ? a.cke - 1 : gk);
-    return a.coords + 3 * (cnode_xy + M * N * (gk - s.cks));
-  };
-  if (cthread) {
-#pragma unroll
-    for (int m = 0; m < 2; m++) {
-      const double *src = coord_ptr(zc0 - 1 + m);
-#pragma unroll
-      for (int d = 0; d < 3; d++) sh_x[m * 324 + 3 * ctid + d] = src[d];
-    }
-  }
-
-  // ---- material prefetch: E, nu of the NEXT quadrature call are loaded one call ahead, so no global
-  //      load latency sits on the per-Gauss-point critical path ----
-  const bool mat_aos = (KIND != KIND_POISSON) && a.mat_layout == 0;
-  const int64_t mat_layer = (M - 1) * (N - 1) * (int64_t)a.mat_stride;
-  const double *matq = a.gp + (gex + (M - 1) * (gey + (N - 1) * (zc0 - 1 - s.mat_e_ks))) * a.mat_stride;
-  auto layer_ok = [&](int64_t L) { return exy_ok && L >= s.els && L < s.ele; };
-  double preE = a.E, preNu = a.nu;
-  if (mat_aos && layer_ok(zc0 - 1)) { preE = matq[96]; preNu = matq[104]; }
-
   for (int st = 0; st < nsteps; st++) {
     const int64_t L = zc0 - 1 + st;  // element layer of this step
-    const bool eok = layer_ok(L);
-    const int xb0 = (st % 3) * 324, xb1 = ((st + 1) % 3) * 324;  // ring slots of node layers L, L+1
-    __syncthreads();  // ring slots of this step are filled; the previous step's staged output has been read
-
-    // next step's new node layer: global loads issued now, parked in registers, stored to the ring late
-    double cnext[3] = {0.0, 0.0, 0.0};
-    const bool cfetch = cthread && st + 1 < nsteps;
-    if (cfetch) {
-      const double *src = coord_ptr(L + 2);
+    // ---- node coordinates of layers L, L+1 (clamped reads; masked elements never use them) ----
+    for (int q = tid; q < 216; q += 256) {
+      const int cz = q / 108, rem = q - 108 * cz, cy = rem / 18, cx = rem - 18 * cy;
+      int64_t gi = i0 - 1 + cx, gj = j0 - 1 + cy, gk = L + cz;
+      gi = gi < 0 ? 0 : (gi > M - 1 ? M - 1 : gi);
+      gj = gj < 0 ? 0 : (gj > N - 1 ? N - 1 : gj);
+      gk = gk < s.cks ? s.cks : (gk > a.cke - 1 ? a.cke - 1 : gk);
+      const int64_t node = gi + M * (gj + N * (gk - s.cks));
 #pragma unroll
-      for (int d = 0; d < 3; d++) cnext[d] = src[d];
+      for (int d = 0; d < 3; d++) sh_x[3 * q + d] = a.coords[3 * node + d];
     }
+    const bool eok = exy_ok && L >= s.els && L < s.ele;
+    const double *matq = nullptr;
+    if (eok && KIND != KIND_POISSON && a.mat_layout == 0)
+      matq = a.gp + (gex + (M - 1) * (gey + (N - 1) * (L - s.mat_e_ks))) * a.mat_stride;
+    __syncthreads();  // coordinates staged; the previous step's staged output has been read
 
     // One record, streamed: coordinates are read from LDS inside the J loop and every gradient pair is
     // stored as soon as it exists, so no 24-double coordinate or 28-double record array stays live next
     // to the 81 accumulators.
-    auto prefetch_material = [&](int p) {  // for the quadrature call that follows call p
-      if (!mat_aos) return;
-      if (p < 7) {
-        if (eok) { preE = matq[96 + p + 1]; preNu = matq[104 + p + 1]; }
-      } else if (st + 1 < nsteps && layer_ok(L + 1)) {
-        preE = matq[mat_layer + 96];
-        preNu = matq[mat_layer + 104];
-      }
-    };
     auto geometry = [&](int p, double2 *recbuf) {
       if (!gthread) return;
       double2 *dst = recbuf + tid;
       if (!eok) {
 #pragma unroll
         for (int q = 0; q < NPAIR; q++) dst[q * SW_NS] = make_double2(0.0, 0.0);
-        prefetch_material(p);
         return;
       }
       const double(*G)[8] = c_tab3.G[p];
       double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
 #pragma unroll
       for (int n = 0; n < 8; n++) {
-        const double *xn = sh_x + (HDK[n] ? xb1 : xb0) + 3 * ((ex + HDI[n]) + 18 * (ey + HDJ[n]));
+        const double *xn = sh_x + 3 * ((ex + HDI[n]) + 18 * ((ey + HDJ[n]) + 6 * HDK[n]));
         const double x0 = xn[0], x1 = xn[1], x2 = xn[2];
 #pragma unroll
         for (int rr = 0; rr < 3; rr++) {
@@ -248,12 +258,13 @@ __global__ __launch_bounds__(256, 2) void k_assemble_sweep(const Slab s, const K
         dst[12 * SW_NS] = make_double2(wJ, 0.0);
         dst[13 * SW_NS] = make_double2(0.0, 0.0);
       } else {
+        double E = a.E, nu = a.nu;
+        if (matq) { E = matq[96 + p]; nu = matq[104 + p]; }
         double d11, d12, d44;
-        scaled_coefs<KIND>(preE, preNu, wJ, d11, d12, d44);
+        scaled_coefs<KIND>(E, nu, wJ, d11, d12, d44);
         dst[12 * SW_NS] = make_double2(d11, d12);
         dst[13 * SW_NS] = make_double2(d44, 0.0);
       }
-      prefetch_material(p);
     };
 
     geometry(0, sh_rec);
@@ -288,46 +299,546 @@ __global__ __launch_bounds__(256, 2) void k_assemble_sweep(const Slab s, const K
         else if (role == 2) sweep_contract<KIND, 0, 0>(rb, myslot, acc);
         else                sweep_contract<KIND, 0, 1>(rb, myslot, acc);
       }
-      if (p == 5 && cfetch) {  // ring slot of layer L+2 = slot of layer L-1: last read in the previous step
-#pragma unroll
-        for (int d = 0; d < 3; d++) sh_x[((st + 2) % 3) * 324 + 3 * ctid + d] = cnext[d];
-      }
       __syncthreads();
     }
-    matq += mat_layer;
 
     // ---- output: roles A (dz=-1), finish (dz=0), D (dz=+1) write one third of their node layer ----
-    if (active && role != 1) {
-      const int dz = (role == 0) ? -1 : (role == 2 ? 0 : 1);
-#pragma unroll
-      for (int c = 0; c < DOF; c++) {
-#pragma unroll
-        for (int t = 0; t < 9; t++)
-#pragma unroll
-          for (int cc = 0; cc < DOF; cc++) stage[lane * CH + t * DOF + cc] = acc[t * DD + c * DOF + cc];
-        __builtin_amdgcn_wave_barrier();
-        for (int rr = 0; rr < 4; rr++) {
-          const int64_t jr = j0 + (((rr & 1) << 1) | (rr >> 1));
-          if (jr >= a.y1) continue;
-          double *base = a.out + (row_start(s, i0, jr, kn, 0) - a.base_off) + (int64_t)c * (27 * DOF) + (dz + 1) * CH;
-          const double *src = stage + rr * (SW_TX * CH);
-#pragma unroll
-          for (int it = 0; it < NIT; it++) {
-            const int idx = lane + 64 * it;
-#if FEMASM_EXP == 1
-            if (idx < nvx * CH) asm volatile("" :: "v"(src[idx]));
-#elif FEMASM_EXP == 4
-            if (idx < nvx * CH && lane == 77) base[goff[it]] = src[idx];
-#else
-            if (idx < nvx * CH) base[goff[it]] = src[idx];
-#endif
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
+    if (active && role != 1)
+      sweep_store_third<KIND>(s, a, acc, stage, lane, i0, j0, kn, (role == 0) ? -1 : (role == 2 ? 0 : 1), nvx);
     // the next step's first __syncthreads orders these LDS reads before the records are rebuilt
   }
+}
+
+// ---------------------------------------------------------------------------
+// Affine fast path.  When an element is a parallelepiped (its twelve edges are three exactly equal
+// quadruples -- true for every element of DMDASetUniformCoordinates meshes, P3:663, S3:1198) the Jacobian
+// is the same at all Gauss points, so with Gauss-point-constant material
+//     sum_p w_p detJ_p g_a(p) g_b(p)^T  =  detJ * iJ R_ab iJ^T ,   R_ab = sum_p dN_a/dxi(p) dN_b/dxi(p)^T ,
+// with R_ab a compile-time reference tensor.  The Gauss-point pipeline of k_assemble_sweep collapses to one
+// record per element (iJ + 3 scaled coefficients) and the per-pair work from 8 x 21 to 75 FMAs.  Results differ
+// from the per-Gauss-point path only by rounding.  The kernel VERIFIES its assumption on every element it
+// touches (exact edge equalities, bitwise-equal E/nu over the Gauss points) and raises a flag otherwise; the
+// host then reruns the general kernel, so this is an optimisation, never an approximation.
+// ---------------------------------------------------------------------------
+struct RefR { double R[8][8][3][3]; };
+// Closed form of the 2x2x2 Gauss sum: with s_a = (+-1,+-1,+-1) the corner signs of node a and
+// f_m = 1 + s_a[m] s_b[m] g^2,  R_ab[k][k] = s_a[k] s_b[k] f_m1 f_m2 / 8  and  R_ab[k][l] = s_a[k] s_b[l] f_m3 / 8.
+// Only five magnitudes occur, so the unrolled contraction keeps them in a handful of scalar registers.
+constexpr RefR make_refR() {
+  RefR o{};
+  const double g2 = GAUSS_G * GAUSS_G;
+  for (int a = 0; a < 8; a++)
+    for (int b = 0; b < 8; b++) {
+      const double sa[3] = {HSX[a], HSY[a], HSZ[a]}, sb[3] = {HSX[b], HSY[b], HSZ[b]};
+      double f[3] = {0, 0, 0};
+      for (int m = 0; m < 3; m++) f[m] = 1.0 + sa[m] * sb[m] * g2;
+      for (int k = 0; k < 3; k++)
+        for (int l = 0; l < 3; l++) {
+          if (k == l) o.R[a][b][k][l] = sa[k] * sb[k] * 0.125 * (f[(k + 1) % 3] * f[(k + 2) % 3]);
+          else        o.R[a][b][k][l] = sa[k] * sb[l] * 0.125 * f[3 - k - l];
+        }
+    }
+  return o;
+}
+constexpr bool refR_matches_gauss_sum() {  // the closed form against the literal sum over Gauss points
+  const RefR o = make_refR();
+  const Tab3 t = make_tab3();
+  for (int a = 0; a < 8; a++)
+    for (int b = 0; b < 8; b++)
+      for (int k = 0; k < 3; k++)
+        for (int l = 0; l < 3; l++) {
+          double v = 0.0;
+          for (int p = 0; p < 8; p++) v += t.G[p][k][a] * t.G[p][l][b];
+          const double d = v - o.R[a][b][k][l];
+          if (d > 1e-16 || d < -1e-16) return false;
+        }
+  return true;
+}
+static_assert(refR_matches_gauss_sum(), "reference tensor R_ab");
+__device__ const RefR d_refR = make_refR();  // const + constant initialiser: folded into literals after unrolling
+
+// ---------------------------------------------------------------------------
+// Row-sweep kernel of the fast path.
+//
+// HBM write rule measured on MI355X (scripts/ubench/store_pattern.hip): a store instruction that leaves a
+// 128-byte line partly written -- to be completed by another instruction, even the next one of the same wave --
+// costs about four full-line writes; the same 4 GB lands at 5.6 TB/s when every instruction covers whole
+// aligned lines and at 2.0-3.0 TB/s when runs of 216 B / 648 B / 1944 B, or a run shifted by 8 B, are written.
+// So the values of a tile row (TX x-consecutive interior nodes = one contiguous run of the CSR value array)
+// are first gathered in LDS in HBM order and then written as 16 B per lane from the 128-byte boundary below
+// the run's start: only the first and last line of a run are partial.
+//
+// Work split: 4 waves.  Waves 0-2 ("row waves") own the accumulators of one CSR row per lane:
+//   elastic  lane = node of the 16x4 tile, wave = dof row c: 81 values = 27 neighbours x 3 column dofs
+//   Poisson  lane = node of one 16x4 third of a 48x4 tile, wave = third: 27 values
+// and contract the records of the 8 elements around the node (element layers kn-1 and kn, both resident in a
+// ring of three record layers), so nothing is carried between steps.  Wave 3 ("record wave") is the only one
+// that reads global memory: it stages node coordinates and (E,nu) one step ahead through registers, tests the
+// premise of the fast path on every element and writes the records of layer kn+1.  gfx9 counts loads and
+// stores in one in-order counter, so a wave that loads waits for its own older stores; here the storing waves
+// never load and the loading wave never stores.
+//
+// Records (per element, pair-SoA rec[pair][slot], slot = ex + SY*ey, 16-byte cells, SY = 8 mod 16 and lane rows
+// mapped {0,2,1,3}: conflict-free ds_read_b128):
+//   elastic (axis-aligned box, 1/J_ii = a_i):  d11 a_i^2 (3), d44 a_i^2 (3), d12 a_i a_j (3), d44 a_i a_j (3)
+//   Poisson (parallelepiped):  C = detJ iJ^T iJ (6)
+// ---------------------------------------------------------------------------
+template <int KIND>
+struct RowSweep {
+  static constexpr int DOF = Traits<KIND>::DOF, DD = DOF * DOF;
+  static constexpr int NSUB = (DOF == 1) ? 3 : 1;  // 16x4 node sub-tiles per tile (row waves = NSUB * DOF = 3)
+  static constexpr int TX = 16 * NSUB, TY = 4;
+  static constexpr int SY = (DOF == 1) ? 56 : 24;
+  static constexpr int NS = SY * (TY + 1);
+  static constexpr int NPA = (DOF == 1) ? 3 : 6;
+  static constexpr int NXX = TX + 2, NXL = NXX * (TY + 2);  // halo'd node layer
+  static constexpr int NEX = TX + 1, NEL = NEX * (TY + 1);  // elements of a tile layer
+  static constexpr int ROW = 27 * DOF;                      // values of an interior CSR row
+  static constexpr int NB = ROW * DOF;                      // values of a node block
+  static constexpr int RUN = TX * NB;                       // doubles of a tile-row run
+  static constexpr int CPASS = (NXL + 63) / 64;             // coordinate passes of the record wave
+  static constexpr int EPASS = (NEL + 63) / 64;             // element passes of the record wave
+};
+constexpr int RS_ZC = 16;  // node layers per workgroup
+
+#if FEMASM_EXP == 3  // phase clocks (profiling build only): PH_ACC(p, id) adds the time since the last mark to phase p
+#define PH_DECL unsigned long long ph_[4] = {0, 0, 0, 0}, ph_n = 0, ph_t = 0
+#define PH_T(id) ph_t = __builtin_readcyclecounter(), ph_n++
+#define PH_ACC(p, id)                                            \
+  do {                                                           \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    ph_[p] += now_ - ph_t;                                       \
+    ph_t = now_;                                                 \
+  } while (0)
+#define PH_FLUSH(base)                                                    \
+  if (lane == 0) {                                                        \
+    atomicAdd(a.bad + (base), ph_n);                                      \
+    for (int q_ = 0; q_ < 4; q_++) atomicAdd(a.bad + (base) + 1 + q_, ph_[q_]); \
+  }
+#else
+#define PH_DECL
+#define PH_T(id)
+#define PH_ACC(p, id)
+#define PH_FLUSH(base)
+#endif
+
+// contributions of the four elements of one element layer to row C of the lane's node.
+// AS = 1: the node is on the top face of these elements (layer kn-1), AS = 0: on their bottom face (layer kn).
+template <int KIND, int C, int AS>
+__device__ inline void row_contract(const double2 *__restrict__ recbuf, int myslot, double *acc) {
+  using R_ = RowSweep<KIND>;
+  constexpr int DOF = R_::DOF, NS = R_::NS, SY = R_::SY;
+#pragma unroll
+  for (int oy = -1; oy <= 0; oy++)
+#pragma unroll
+    for (int ox = -1; ox <= 0; ox++) {
+      const double2 *rp = recbuf + (myslot + ox + SY * oy);
+      const int ia = hex_idx(-ox, -oy, AS);
+      if constexpr (KIND == KIND_POISSON) {
+        const double2 c0 = rp[0], c1 = rp[NS], c2 = rp[2 * NS];
+        const double C00 = c0.x, C01 = c0.y, C02 = c1.x, C11 = c1.y, C12 = c2.x, C22 = c2.y;
+#pragma unroll
+        for (int bz = 0; bz <= 1; bz++)
+#pragma unroll
+          for (int by = 0; by <= 1; by++)
+#pragma unroll
+            for (int bx = 0; bx <= 1; bx++) {
+              const double(*R)[3] = d_refR.R[ia][hex_idx(bx, by, bz)];
+              const int t = ((bz - AS + 1) * 3 + (oy + by + 1)) * 3 + (ox + bx + 1);
+              double v = acc[t];
+              v = fma(R[0][0], C00, v);
+              v = fma(R[1][1], C11, v);
+              v = fma(R[2][2], C22, v);
+              v = fma(R[0][1] + R[1][0], C01, v);
+              v = fma(R[0][2] + R[2][0], C02, v);
+              v = fma(R[1][2] + R[2][1], C12, v);
+              acc[t] = v;
+            }
+      } else {
+        const double2 r0 = rp[0], r1 = rp[NS], r2 = rp[2 * NS], r3 = rp[3 * NS], r4 = rp[4 * NS], r5 = rp[5 * NS];
+        const double pd[3] = {r0.x, r0.y, r1.x};  // d11 a_i^2
+        const double pe[3] = {r1.y, r2.x, r2.y};  // d44 a_i^2
+        const double po[3] = {r3.x, r3.y, r4.x};  // d12 a_i a_j for (i,j) = (0,1), (0,2), (1,2)
+        const double pq[3] = {r4.y, r5.x, r5.y};  // d44 a_i a_j
+        constexpr int C1 = (C + 1) % 3, C2 = (C + 2) % 3;
+#pragma unroll
+        for (int bz = 0; bz <= 1; bz++)
+#pragma unroll
+          for (int by = 0; by <= 1; by++)
+#pragma unroll
+            for (int bx = 0; bx <= 1; bx++) {
+              const double(*R)[3] = d_refR.R[ia][hex_idx(bx, by, bz)];
+              const int t = ((bz - AS + 1) * 3 + (oy + by + 1)) * 3 + (ox + bx + 1);
+#pragma unroll
+              for (int cc = 0; cc < DOF; cc++) {
+                double v = acc[t * DOF + cc];
+                if (cc == C) {
+                  v = fma(R[C][C], pd[C], v);
+                  v = fma(R[C1][C1], pe[C1], v);
+                  v = fma(R[C2][C2], pe[C2], v);
+                } else {
+                  v = fma(R[C][cc], po[C + cc - 1], v);
+                  v = fma(R[cc][C], pq[C + cc - 1], v);
+                }
+                acc[t * DOF + cc] = v;
+              }
+            }
+      }
+    }
+}
+
+// steps of one row wave: wave index wv (0..2), row C (elastic) or third wv of the tile (Poisson)
+// Barrier among the three row waves only (the record wave keeps working): an LDS arrival counter that every
+// row wave bumps once per call and then polls.  All waves of a workgroup are resident, so the poll always
+// makes progress; the guard turns a logic error into a reported failure instead of a hung queue.
+__device__ inline void row_waves_sync(unsigned *cnt, unsigned &epoch, int lane, unsigned long long *bad) {
+  epoch += 3;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's LDS traffic has completed
+  if (lane == 0) atomicAdd(cnt, 1u);
+  int guard = 0;
+  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch) {
+    if (++guard > (1 << 16)) {
+      if (lane == 0) atomicAdd(bad, 1ULL);
+      break;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <int KIND, int C>
+__device__ inline void rowsweep_row_wave(const Slab &s, const KArgs &a, const double2 *sh_rec, double *sh_stage,
+                                         unsigned *sh_cnt, int wv, int lane, int64_t i0, int64_t j0, int64_t zc0,
+                                         int nz) {
+  using R_ = RowSweep<KIND>;
+  constexpr int DOF = R_::DOF, ROW = R_::ROW, NB = R_::NB, NS = R_::NS, NPA = R_::NPA, SY = R_::SY;
+  const int sub = (DOF == 1) ? wv : 0;
+  const int nvx = (a.x1 - i0 < R_::TX) ? (int)(a.x1 - i0) : R_::TX;  // valid nodes of the tile in x
+  int q3 = 0;                                                         // st % 3
+  unsigned epoch = 0;
+  PH_DECL;
+  for (int st = 0; st < nz; st++) {
+    const int64_t kn = zc0 + st;
+    int ln = lane;  // opaque per step: lane-derived addressing is recomputed, not hoisted and spilled
+    asm volatile("" : "+v"(ln));
+    const int lx = ln & 15, r = ln >> 4, ly = ((r & 1) << 1) | (r >> 1);
+    const int myslot = (16 * sub + lx + 1) + SY * (ly + 1);
+    const int q3a = (q3 == 2) ? 0 : q3 + 1;
+    PH_T(0);
+    __syncthreads();  // records of element layers kn-1 (ring slot q3) and kn (slot q3a) are complete
+    PH_ACC(0, 1);
+    double acc[ROW];
+#pragma unroll
+    for (int q = 0; q < ROW; q++) acc[q] = 0.0;
+    row_contract<KIND, C, 1>(sh_rec + q3 * (NPA * NS), myslot, acc);
+    row_contract<KIND, C, 0>(sh_rec + q3a * (NPA * NS), myslot, acc);
+    const int ct = 64 * wv + ln;  // 0..191 over the row waves
+    PH_ACC(1, 2);
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+      row_waves_sync(sh_cnt, epoch, ln, a.bad);  // the previous run has left the staging buffer
+      PH_ACC(0, 3);
+      if (ly == rr) {
+        double *dst = sh_stage + (16 * sub + lx) * NB + C * ROW;
+#pragma unroll
+        for (int q = 0; q < ROW; q++) dst[q] = acc[q];
+      }
+      PH_ACC(2, 4);
+      row_waves_sync(sh_cnt, epoch, ln, a.bad);  // run complete in LDS, in HBM order
+      PH_ACC(0, 5);
+      const int64_t jr = j0 + rr;
+      if (jr < a.y1) {
+        const int n = nvx * NB;
+        double *runp = a.out + (row_start(s, i0, jr, kn, 0) - a.base_off);
+        const int head = (int)((reinterpret_cast<uintptr_t>(runp) & 127) >> 3);  // doubles above a line boundary
+        const int nchunk = (head + n + 1) >> 1;
+        constexpr int NIT = (R_::RUN / 2 + 8 + 191) / 192;
+        double2 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {  // chunk q = the q-th 16 bytes from that boundary; LDS reads first
+          const int s0 = 2 * (ct + 192 * it) - head;
+          const int sa = s0 < 0 ? 0 : s0, sb = s0 + 1 < n ? s0 + 1 : n - 1;
+          v[it] = make_double2(sh_stage[sa], sh_stage[sb]);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+          const int q = ct + 192 * it, s0 = 2 * q - head;
+          if (q < nchunk) {
+            if (s0 >= 0 && s0 + 1 < n) {
+#if FEMASM_EXP == 1
+              asm volatile("" ::"v"(v[it].x), "v"(v[it].y));
+#else
+              *reinterpret_cast<double2 *>(runp + s0) = v[it];
+#endif
+            } else if (s0 == -1) {
+              runp[0] = v[it].y;
+            } else if (s0 == n - 1) {
+              runp[s0] = v[it].x;
+            }
+          }
+        }
+      }
+      PH_ACC(3, 6);
+    }
+    q3 = q3a;
+  }
+  PH_FLUSH(8);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256, 2) void k_assemble_rowsweep(const Slab s, const KArgs a) {
+  using R_ = RowSweep<KIND>;
+  constexpr int DOF = R_::DOF, NS = R_::NS, NPA = R_::NPA, SY = R_::SY, NXX = R_::NXX, NXL = R_::NXL;
+  constexpr int NEX = R_::NEX, NEL = R_::NEL, CPASS = R_::CPASS, EPASS = R_::EPASS;
+  constexpr bool HASMAT = (KIND != KIND_POISSON);
+
+  __shared__ double2 sh_rec[3 * NPA * NS];  // ring: element layer L0+q in slot q % 3
+  __shared__ double sh_stage[R_::RUN];      // one tile-row run in HBM order
+  __shared__ double sh_x[3][NXL * 3];       // ring of node layers (record wave only): layer L0+q in slot q % 3
+  __shared__ unsigned sh_cnt;               // arrival counter of row_waves_sync
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t M = s.dim[0], N = s.dim[1];
+  const int64_t i0 = a.x0 + (int64_t)blockIdx.x * R_::TX, j0 = a.y0 + (int64_t)blockIdx.y * R_::TY;
+  const int64_t zc0 = a.s0 + (int64_t)blockIdx.z * RS_ZC;
+  const int64_t zc1 = (zc0 + RS_ZC < a.s1) ? zc0 + RS_ZC : a.s1;
+  const int nz = (int)(zc1 - zc0);
+  const int64_t L0 = zc0 - 1;
+
+  if (tid == 0) sh_cnt = 0;
+  if (wu < 3) {
+    __syncthreads();  // matches the record wave's prologue
+    if constexpr (DOF == 1) {
+      rowsweep_row_wave<KIND, 0>(s, a, sh_rec, sh_stage, &sh_cnt, wu, lane, i0, j0, zc0, nz);
+    } else {
+      if (wu == 0) rowsweep_row_wave<KIND, 0>(s, a, sh_rec, sh_stage, &sh_cnt, 0, lane, i0, j0, zc0, nz);
+      else if (wu == 1) rowsweep_row_wave<KIND, 1>(s, a, sh_rec, sh_stage, &sh_cnt, 1, lane, i0, j0, zc0, nz);
+      else rowsweep_row_wave<KIND, 2>(s, a, sh_rec, sh_stage, &sh_cnt, 2, lane, i0, j0, zc0, nz);
+    }
+    return;
+  }
+
+  // ------------------------------- record wave -------------------------------
+  const bool aos = HASMAT && a.mat_layout == 0;
+  auto load_layer = [&](int64_t gk, double (*cr)[3], int ln) {  // node layer gk of the halo'd tile -> registers
+    gk = gk < s.cks ? s.cks : (gk > a.cke - 1 ? a.cke - 1 : gk);
+#pragma unroll
+    for (int ps = 0; ps < CPASS; ps++) {
+      const int q = ln + 64 * ps;
+      if (q < NXL) {
+        const int cy = q / NXX, cx = q - NXX * cy;
+        int64_t gi = i0 - 1 + cx, gj = j0 - 1 + cy;
+        gi = gi < 0 ? 0 : (gi > M - 1 ? M - 1 : gi);
+        gj = gj < 0 ? 0 : (gj > N - 1 ? N - 1 : gj);
+        const double *src = a.coords + 3 * (gi + M * (gj + N * (gk - s.cks)));
+#pragma unroll
+        for (int d = 0; d < 3; d++) cr[ps][d] = src[d];
+      }
+    }
+  };
+  auto commit_layer = [&](int slot, const double (*cr)[3], int ln) {
+#pragma unroll
+    for (int ps = 0; ps < CPASS; ps++) {
+      const int q = ln + 64 * ps;
+      if (q < NXL) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) sh_x[slot][3 * q + d] = cr[ps][d];
+      }
+    }
+  };
+  // E[8], nu[8] of the elements of layer L: one element per lane and pass (its 128 contiguous bytes)
+  auto load_mat = [&](int64_t L, double (*mraw)[16], int ln) {
+    if (!aos) return;
+#pragma unroll
+    for (int ps = 0; ps < EPASS; ps++) {
+      const int e = ln + 64 * ps, my = e / NEX, mx = e - NEX * my;
+      const int64_t mgx = i0 - 1 + mx, mgy = j0 - 1 + my;
+      const bool ok = e < NEL && mgx >= 0 && mgx < M - 1 && mgy >= 0 && mgy < N - 1 && L >= s.els && L < s.ele;
+      if (ok) {
+        const double *mq = a.gp + (mgx + (M - 1) * (mgy + (N - 1) * (L - s.mat_e_ks))) * a.mat_stride + 96;
+#pragma unroll
+        for (int q = 0; q < 16; q++) mraw[ps][q] = mq[q];
+      }
+    }
+  };
+  // all eight E and all eight nu of an element must be bitwise equal, else the fast path does not apply
+  auto reduce_mat = [&](const double (*mraw)[16], double *mE, double *mNu) {
+    if (!aos) return;
+#pragma unroll
+    for (int ps = 0; ps < EPASS; ps++) {
+      bool same = true;
+#pragma unroll
+      for (int q = 1; q < 8; q++) same = same && mraw[ps][q] == mraw[ps][0] && mraw[ps][8 + q] == mraw[ps][8];
+      mE[ps] = mraw[ps][0];
+      mNu[ps] = same ? mraw[ps][8] : __builtin_nan("");  // NaN marks "varies inside the element"
+    }
+  };
+  // records of element layer L from node layers xb (bottom) and xt (top); verifies the premise of the fast path
+  auto build_records = [&](int64_t L, const double *xb, const double *xt, double2 *recbuf, int ln, int ps, double mE,
+                           double mNu) {
+    {
+      const int e = ln + 64 * ps;
+      if (e >= NEL) return;
+      const int ey = e / NEX, ex = e - NEX * ey;
+      const int64_t gex = i0 - 1 + ex, gey = j0 - 1 + ey;
+      double2 *dst = recbuf + (ex + SY * ey);
+      const bool eok = gex >= 0 && gex < M - 1 && gey >= 0 && gey < N - 1 && L >= s.els && L < s.ele;
+      if (!eok) {
+#pragma unroll
+        for (int q = 0; q < NPA; q++) dst[q * NS] = make_double2(0.0, 0.0);
+        return;
+      }
+      double x[8][3];
+#pragma unroll
+      for (int n = 0; n < 8; n++) {
+        const double *xn = (HDK[n] ? xt : xb) + 3 * ((ex + HDI[n]) + NXX * (ey + HDJ[n]));
+#pragma unroll
+        for (int d = 0; d < 3; d++) x[n][d] = xn[d];
+      }
+      // edges: xi-direction 0->3, 1->2, 4->7, 5->6 ; eta 0->1, 3->2, 4->5, 7->6 ; zeta 0->4, 1->5, 2->6, 3->7
+      bool affine = true;
+      double J[3][3];
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        const double e1 = x[3][d] - x[0][d], e2 = x[1][d] - x[0][d], e3 = x[4][d] - x[0][d];
+        affine = affine && (x[2][d] - x[1][d] == e1) && (x[7][d] - x[4][d] == e1) && (x[6][d] - x[5][d] == e1);
+        affine = affine && (x[2][d] - x[3][d] == e2) && (x[5][d] - x[4][d] == e2) && (x[6][d] - x[7][d] == e2);
+        affine = affine && (x[5][d] - x[1][d] == e3) && (x[6][d] - x[2][d] == e3) && (x[7][d] - x[3][d] == e3);
+        J[0][d] = 0.5 * e1;  // J_rc = d x_c / d xi_r
+        J[1][d] = 0.5 * e2;
+        J[2][d] = 0.5 * e3;
+      }
+      if constexpr (HASMAT) {  // elastic: axis-aligned boxes only
+        double E = a.E, nu = a.nu;
+        if (aos) {
+          E = mE;
+          nu = mNu;
+          affine = affine && (mNu == mNu);
+        }
+        affine = affine && J[0][1] == 0.0 && J[0][2] == 0.0 && J[1][0] == 0.0 && J[1][2] == 0.0 && J[2][0] == 0.0 &&
+                 J[2][1] == 0.0;
+        if (!affine) atomicAdd(a.bad + 1, 1ULL);
+        const double wJ = 1.0 * (J[0][0] * J[1][1] * J[2][2]);
+        if (!(wJ > 0.0)) atomicAdd(a.bad, 1ULL);
+        const double ai[3] = {1.0 / J[0][0], 1.0 / J[1][1], 1.0 / J[2][2]};
+        double d11, d12, d44;
+        scaled_coefs<KIND>(E, nu, wJ, d11, d12, d44);
+        const double q0 = ai[0] * ai[0], q1 = ai[1] * ai[1], q2 = ai[2] * ai[2];
+        const double q01 = ai[0] * ai[1], q02 = ai[0] * ai[2], q12 = ai[1] * ai[2];
+        dst[0] = make_double2(d11 * q0, d11 * q1);
+        if constexpr (NPA == 6) {
+          dst[NS] = make_double2(d11 * q2, d44 * q0);
+          dst[2 * NS] = make_double2(d44 * q1, d44 * q2);
+          dst[3 * NS] = make_double2(d12 * q01, d12 * q02);
+          dst[4 * NS] = make_double2(d12 * q12, d44 * q01);
+          dst[5 * NS] = make_double2(d44 * q02, d44 * q12);
+        }
+      } else {  // Poisson: any parallelepiped
+        if (!affine) atomicAdd(a.bad + 1, 1ULL);
+        double iJ[3][3];
+        const double t4 = J[2][0] * J[0][1], t6 = J[2][0] * J[0][2], t8 = J[1][0] * J[0][1];
+        const double t10 = J[1][0] * J[0][2], t12 = J[0][0] * J[1][1], t14 = J[0][0] * J[1][2];
+        const double t17 =
+            1.0 / (t4 * J[1][2] - t6 * J[1][1] - t8 * J[2][2] + t10 * J[2][1] + t12 * J[2][2] - t14 * J[2][1]);
+        iJ[0][0] = (J[1][1] * J[2][2] - J[1][2] * J[2][1]) * t17;
+        iJ[0][1] = -(J[0][1] * J[2][2] - J[0][2] * J[2][1]) * t17;
+        iJ[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * t17;
+        iJ[1][0] = -(-J[2][0] * J[1][2] + J[1][0] * J[2][2]) * t17;
+        iJ[1][1] = (-t6 + J[0][0] * J[2][2]) * t17;
+        iJ[1][2] = -(-t10 + t14) * t17;
+        iJ[2][0] = (-J[2][0] * J[1][1] + J[1][0] * J[2][1]) * t17;
+        iJ[2][1] = -(-t4 + J[0][0] * J[2][1]) * t17;
+        iJ[2][2] = (-t8 + t12) * t17;
+        const double det = J[0][0] * J[1][1] * J[2][2] - J[0][0] * J[1][2] * J[2][1] - J[1][0] * J[0][1] * J[2][2] +
+                           J[1][0] * J[0][2] * J[2][1] + J[2][0] * J[0][1] * J[1][2] - J[2][0] * J[0][2] * J[1][1];
+        const double wJ = 1.0 * det;
+        if (!(wJ > 0.0)) atomicAdd(a.bad, 1ULL);
+        // physical gradient g_i = sum_k iJ[i][k] ghat_k  ->  g_a.g_b = ghat_a^T (iJ^T iJ) ghat_b
+        double Cm[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+          for (int l = k; l < 3; l++)
+            Cm[k][l] = (iJ[0][k] * iJ[0][l] + iJ[1][k] * iJ[1][l] + iJ[2][k] * iJ[2][l]) * wJ;
+        dst[0] = make_double2(Cm[0][0], Cm[0][1]);
+        dst[NS] = make_double2(Cm[0][2], Cm[1][1]);
+        dst[2 * NS] = make_double2(Cm[1][2], Cm[2][2]);
+      }
+    }
+  };
+
+  // Two register sets: what step st commits was requested during step st-2.  The compute unit's memory queue
+  // is a FIFO shared with the row waves' stores, so under a store-bound load a read waits about one step.
+  double cr[2][CPASS][3], mraw[2][EPASS][16], mE[EPASS], mNu[EPASS];
+#pragma unroll
+  for (int p = 0; p < 2; p++) {
+#pragma unroll
+    for (int ps = 0; ps < CPASS; ps++)
+#pragma unroll
+      for (int d = 0; d < 3; d++) cr[p][ps][d] = 0.0;
+#pragma unroll
+    for (int ps = 0; ps < EPASS; ps++)
+#pragma unroll
+      for (int q = 0; q < 16; q++) mraw[p][ps][q] = 0.0;
+  }
+#pragma unroll
+  for (int ps = 0; ps < EPASS; ps++) mE[ps] = mNu[ps] = 0.0;
+  auto lds_fence = [&]() {  // LDS written by this wave is read by other lanes of this wave: the LDS queue of a
+    asm volatile("" ::: "memory");    // wave is in order, only the compiler has to keep the order
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  // prologue: node layers L0..L0+2, records of element layers L0 and L0+1; requests for steps 0 and 1
+#pragma unroll 1
+  for (int q = 0; q < 3; q++) {
+    load_layer(L0 + q, cr[0], lane);
+    commit_layer(q, cr[0], lane);
+  }
+#pragma unroll 1
+  for (int q = 0; q < 2; q++) {
+    load_mat(L0 + q, mraw[0], lane);
+    reduce_mat(mraw[0], mE, mNu);
+    lds_fence();
+#pragma unroll
+    for (int ps = 0; ps < EPASS; ps++)
+      build_records(L0 + q, sh_x[q], sh_x[q + 1], sh_rec + q * (NPA * NS), lane, ps, mE[ps], mNu[ps]);
+  }
+  load_layer(L0 + 3, cr[0], lane);
+  load_mat(L0 + 2, mraw[0], lane);
+  load_layer(L0 + 4, cr[1], lane);
+  load_mat(L0 + 3, mraw[1], lane);
+  __syncthreads();
+
+  int q3 = 0;  // st % 3
+  PH_DECL;
+  auto step = [&](int st, double (*crp)[3], double (*mrawp)[16]) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int q3a = (q3 == 2) ? 0 : q3 + 1, q3b = (q3a == 2) ? 0 : q3a + 1;
+    PH_T(0);
+    __syncthreads();
+    PH_ACC(0, 1);
+    if (st + 1 < nz) {  // records of element layer L0+st+2, read by the row waves from the next step on
+      commit_layer(q3, crp, ln);  // node layer L0+st+3 replaces layer L0+st
+      reduce_mat(mrawp, mE, mNu);
+      if (st + 3 < nz) {
+        load_layer(L0 + st + 5, crp, ln);
+        load_mat(L0 + st + 4, mrawp, ln);
+      }
+      lds_fence();
+      PH_ACC(1, 2);
+#pragma unroll
+      for (int ps = 0; ps < EPASS; ps++)
+        build_records(L0 + st + 2, sh_x[q3b], sh_x[q3], sh_rec + q3b * (NPA * NS), ln, ps, mE[ps], mNu[ps]);
+      PH_ACC(2, 3);
+    }
+    q3 = q3a;
+  };
+  for (int st = 0; st < nz; st += 2) {
+    step(st, cr[0], mraw[0]);
+    if (st + 1 < nz) step(st + 1, cr[1], mraw[1]);
+  }
+  PH_FLUSH(16);
 }
 
 // ---------------------------------------------------------------------------

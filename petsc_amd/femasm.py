@@ -30,7 +30,7 @@ EXPORTS = [
     "femasm_plan_create", "femasm_plan_destroy", "femasm_plan_set_stream", "femasm_pattern",
     "femasm_pattern_copy", "femasm_scatter_map", "femasm_assemble_system", "femasm_interface_buffers",
     "femasm_interface_set_buffers", "femasm_interface_apply", "femasm_compress_bc_rows", "femasm_plan_sync", "femasm_last_error",
-    "femasm_version",
+    "femasm_version", "femasm_plan_set_fast_path", "femasm_plan_get_fast_path",
 ]
 
 
@@ -145,6 +145,15 @@ class Plan:
 
     def set_stream(self, stream_handle):
         _check(load().femasm_plan_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def set_fast_path(self, level):
+        """2 = box kernel, 1 = affine kernel, 0 = general kernel (see include/femasm.h)."""
+        _check(load().femasm_plan_set_fast_path(self._h, C.c_int(int(level))))
+
+    def fast_path(self):
+        lv = C.c_int()
+        _check(load().femasm_plan_get_fast_path(self._h, C.byref(lv)))
+        return lv.value
 
     def sync(self):
         _check(load().femasm_plan_sync(self._h))

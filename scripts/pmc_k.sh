@@ -11,7 +11,7 @@ import csv,glob,sys,collections
 d=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1]+'/**/*counter_collection.csv',recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'k_assemble_rows' in r['Kernel_Name']:
+        if 'k_assemble' in r['Kernel_Name'] or 'k_bc_rows' in r['Kernel_Name']:
             d[r['Kernel_Name'][:60]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k,v in d.items():
     print(k)

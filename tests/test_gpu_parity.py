@@ -272,3 +272,101 @@ def test_mismatched_bc_kind_is_rejected(env):
         plan.assemble_system(vals, None, bc=F.BC_S3_ALLFACES_EXACT)
     assert ei.value.code == 1
     plan.close()
+
+
+# ---- specialised stiffness kernels (femasm_plan_set_fast_path): premise tests and fallback ----
+def _s3_case_from_coords(env, dims, coords, vary_material=False):
+    O, F = env["O"], env["F"]
+    M, N, P = dims
+    rp, ci = O.pattern(3, 3, M, N, P)
+    props = O.props_s3(M - 1, N - 1, P - 1, coords).reshape(-1, 400)
+    if vary_material:
+        rng = np.random.default_rng(3)
+        props[:, 96:104] = rng.uniform(50, 150, size=(props.shape[0], 8))
+    props = props.reshape(-1)
+    K, b = O.assemble_elastic3d(M, N, P, coords, props, rp, ci)
+    O.bc_s3(M, N, P, coords, rp, ci, K, b)
+    return dict(problem=F.ELASTIC3D_Q1, dims=(M, N, P), coords=coords, props=props, stride=400,
+                bc=F.BC_S3_ALLFACES_EXACT, rp=rp, ci=ci, K=K, b=b)
+
+
+def _sheared(O, M, N, P):
+    """Parallelepiped elements with exactly representable coordinates (h = 1/8, dyadic shear)."""
+    c = O.uniform_coords(3, M, N, P).reshape(-1, 3)
+    A = np.array([[1.0, 0.25, 0.5], [0.0, 1.0, 0.25], [0.125, 0.0, 1.0]])
+    return (c @ A.T).reshape(-1).copy()
+
+
+def test_box_kernel_is_kept_on_uniform_anisotropic_mesh(env):
+    case = make_case(env, "s3", (9, 7, 6), perturb=False)
+    plan, vals, b = gpu_assemble(env, case)
+    assert plan.fast_path() == 2
+    assert rel(vals, case["K"]) <= TOL and rel(b, case["b"]) <= TOL
+    plan.close()
+
+
+def test_sheared_mesh_elastic_falls_back_poisson_stays_fast(env):
+    O = env["O"]
+    dims = (9, 9, 9)
+    case = _s3_case_from_coords(env, dims, _sheared(O, *dims))
+    plan, vals, b = gpu_assemble(env, case)
+    assert plan.fast_path() == 0  # parallelepipeds are not boxes
+    assert rel(vals, case["K"]) <= TOL and rel(b, case["b"]) <= TOL
+    plan.close()
+    # Poisson's fast kernel takes any parallelepiped
+    M, N, P = dims
+    rp, ci = O.pattern(3, 1, M, N, P)
+    K, bb = O.assemble_poisson3d(M, N, P, case["coords"], rp, ci)
+    pc = dict(problem=env["F"].POISSON3D_Q1, dims=dims, coords=case["coords"], props=None, stride=0,
+              bc=env["F"].BC_POISSON_INLOOP, rp=rp, ci=ci, K=K, b=bb)
+    plan, vals, b = gpu_assemble(env, pc)
+    assert plan.fast_path() >= 1
+    assert rel(vals, K) <= TOL and rel(b, bb) <= TOL
+    plan.close()
+
+
+@pytest.mark.parametrize("kind", ["p3", "s3"])
+def test_general_geometry_drops_to_the_general_kernel(env, kind):
+    case = make_case(env, kind, (8, 7, 9), perturb=True)
+    plan, vals, b = gpu_assemble(env, case)
+    assert plan.fast_path() == 0
+    assert rel(vals, case["K"]) <= TOL
+    plan.close()
+
+
+def test_one_moved_interior_node_is_enough_to_fall_back(env):
+    O = env["O"]
+    dims = (9, 9, 9)
+    c = O.uniform_coords(3, *dims).reshape(-1, 3)
+    c[4 + 9 * (4 + 9 * 4)] += [0.01, -0.02, 0.015]
+    case = _s3_case_from_coords(env, dims, c.reshape(-1).copy())
+    plan, vals, b = gpu_assemble(env, case)
+    assert plan.fast_path() == 0
+    assert rel(vals, case["K"]) <= TOL
+    plan.close()
+
+
+def test_material_varying_inside_an_element_falls_back(env):
+    O = env["O"]
+    dims = (7, 6, 8)
+    case = _s3_case_from_coords(env, dims, O.uniform_coords(3, *dims), vary_material=True)
+    plan, vals, b = gpu_assemble(env, case)
+    assert plan.fast_path() == 0
+    assert rel(vals, case["K"]) <= TOL
+    plan.close()
+
+
+@pytest.mark.parametrize("kind", ["p3", "s3"])
+@pytest.mark.parametrize("level", [0, 1, 2])
+def test_all_kernel_levels_agree_with_the_oracle_on_a_uniform_mesh(env, kind, level):
+    torch, F, dev = env["torch"], env["F"], env["dev"]
+    case = make_case(env, kind, (20, 9, 19), perturb=False)
+    M, N, P = case["dims"]
+    plan = F.Plan(case["problem"], M, N, P, coords=torch.from_numpy(case["coords"]).to(dev))
+    plan.set_fast_path(level)
+    vals = torch.full((plan.nnz,), float("nan"), dtype=torch.float64, device=dev)
+    mat = None if case["props"] is None else torch.from_numpy(case["props"]).to(dev)
+    plan.assemble_system(vals, None, material=mat, stride=case["stride"], bc=case["bc"])
+    assert plan.fast_path() == level
+    assert rel(vals.cpu().numpy(), case["K"]) <= TOL
+    plan.close()
