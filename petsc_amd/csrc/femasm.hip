@@ -212,15 +212,17 @@ int launch_rhs(femasm_plan *p, const femasm_material *mat, int bc, double *out, 
   a.s0 = s0;
   a.s1 = s1;
   a.nel = p->nel;
+  a.nelp = (p->nel + 15) & ~(int64_t)15;
   a.mat_layout = mat ? mat->layout : FEMASM_MAT_UNIFORM;
   a.mat_stride = mat ? mat->stride : 0;
   a.bc = bc;
   a.iface = iface;
   if (do_elem && p->nel > 0) {
-    if (KIND == KIND_ELASTIC)
-      hipLaunchKernelGGL(k_rhs_elem_elastic_coop,
-                         dim3(nblk(p->s.dim[0] - 1, 8), (unsigned)(p->s.dim[1] - 1), (unsigned)(p->s.ele - p->s.els)),
-                         dim3(256), 0, p->stream, p->s, a);
+    if (KIND == KIND_ELASTIC) {
+      const int64_t ngroups = (p->nel + 15) / 16;
+      hipLaunchKernelGGL(k_rhs_elem_elastic_coop, dim3((unsigned)(ngroups < 2048 ? ngroups : 2048)), dim3(256), 0,
+                         p->stream, p->s, a);
+    }
     else
       hipLaunchKernelGGL(k_rhs_elem<KIND>, dim3(nblk(p->nel)), dim3(256), 0, p->stream, p->s, a);
     HIPCHK(hipGetLastError());
@@ -324,7 +326,7 @@ int femasm_plan_create(const femasm_mesh *mesh, const femasm_quad *quad, int dev
   PCHK(hipMalloc(&p->colidx, (size_t)(p->nnz > 0 ? p->nnz : 1) * sizeof(int32_t)));
   PCHK(hipMalloc(&p->bad, 32 * sizeof(unsigned long long)));  // [0] bad detJ, [1] fast-path premise failures, rest: profiling builds
   PCHK(hipMemsetAsync(p->bad, 0, 32 * sizeof(unsigned long long), p->stream));
-  PCHK(hipMalloc(&p->elemF, (size_t)(p->nel > 0 ? p->nel : 1) * nfe * sizeof(double)));
+  PCHK(hipMalloc(&p->elemF, (size_t)(((p->nel > 0 ? p->nel : 1) + 15) & ~(int64_t)15) * nen * dof * sizeof(double)));
 
   // interface buffers: rows of node layer ks-1 (owed to the rank below) and of ke-1 (owed to us)
   if (s.ks > 0) {

@@ -552,7 +552,8 @@ __global__ __launch_bounds__(256, 2) void k_assemble_rows(const Slab s, const KA
 struct RArgs {
   const double *coords;
   const double *gp;
-  double *elemF;          // [nel_local][NFE]
+  double *elemF;          // element vectors, component-major: F[t][e], t = local node * dof + c, rows of nelp
+  int64_t nelp;           // nel rounded up to a multiple of 16 (rows start on 128-byte lines)
   double *out;            // b of the processed rows
   const double *recv;     // interface_apply
   int64_t cke;
@@ -660,112 +661,156 @@ __global__ __launch_bounds__(256) void k_rhs_elem(const Slab s, const RArgs a) {
       }
     }
   }
-  double *o = a.elemF + e * NFE;
+  // component-major: consecutive lanes (elements) write consecutive doubles, whole 128-byte lines per instruction
+  constexpr int NOUT = T::NEN * T::DOF;
 #pragma unroll
-  for (int q = 0; q < NFE; q++) o[q] = F[q];
+  for (int q = 0; q < NOUT; q++) {
+    if constexpr (KIND == KIND_ELASTIC) a.elemF[q * a.nelp + e] = F[q] + F[NOUT + q];
+    else a.elemF[q * a.nelp + e] = F[q];
+  }
 }
 
 // ---------------------------------------------------------------------------
-// RHS, pass 1 for S3/R3, cooperative form: 32 lanes per element, 8 elements per workgroup.
-// Lane q < 24 owns face Gauss point q (traction sigma.n * face Jacobian, S3:568-648), lane
-// q >= 24 owns volume Gauss point q-24 (w*detJ * f, S3:534-545); the 2.3 KB of per-element
-// AoS inputs are read as contiguous runs across lanes.  Then lane q < 24 = dof (node q/3,
-// component q%3) sums its 8 + 24 terms in Gauss-point order and writes Fe / Ge contiguously.
+// RHS, pass 1 for S3/R3, cooperative streaming form.  A workgroup walks over groups of 16 consecutive
+// elements, 8 at a time with 32 lanes per element; the 2.3 KB of per-element AoS inputs (doubles [112,400) =
+// E_B[24] nu_B[24] fx[8] fy[8] fz[8] gx[72] gy[72] gz[72]) are read as contiguous 16-byte-per-lane runs, one
+// half-group ahead through registers.  Lane q < 24 owns face Gauss point q (traction sigma.n * face Jacobian,
+// S3:568-648), lane q >= 24 owns volume Gauss point q-24 (w*detJ * f, S3:534-545); then lane q < 24 = dof
+// (node q/3, component q%3) sums its 8 + 24 terms in Gauss-point order.  Fe + Ge of the 16 elements leave as 24
+// full 128-byte lines of the component-major element-vector array.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rhs_elem_elastic_coop(const Slab s, const RArgs a) {
-  // per element: AoS doubles [112,400) = E_B[24] nu_B[24] fx[8] fy[8] fz[8] gx[72] gy[72] gz[72]
   __shared__ __attribute__((aligned(16))) double sh_in[8][288];
   __shared__ double sh_xc[8][24];
   __shared__ double sh_t[8][24][3];
   __shared__ double sh_u[8][8][3];
   __shared__ double sh_N[8][8];
   __shared__ double sh_NF[24][8];
+  __shared__ __attribute__((aligned(16))) double sh_out[24][16];
   const int tid = threadIdx.x, el = tid >> 5, q = tid & 31;
-  // grid = (ceil(mx/8), my, element layers): no integer division on the hot path
   const int64_t M = s.dim[0], N = s.dim[1];
   const int64_t mx = M - 1, my = N - 1;
-  const int64_t ex = (int64_t)blockIdx.x * 8 + el, ey = blockIdx.y, ez = s.els + blockIdx.z;
-  const bool live = ex < mx;
-  const int64_t e = ex + mx * (ey + my * (int64_t)blockIdx.z);
+  const int64_t ngroups = (a.nel + 15) >> 4;
   const bool aos = a.mat_layout == 0;
+  const bool wide = (a.mat_stride & 1) == 0;  // element blocks keep the base's 16-byte alignment
   if (tid < 64) sh_N[tid >> 3][tid & 7] = c_tab3.N[tid >> 3][tid & 7];
   else sh_NF[(tid - 64) >> 3][tid & 7] = c_tab3.NF[(tid - 64) >> 3][tid & 7];
-  if (live) {
+
+  double2 pin[5];
+  double pxc = 0.0;
+#pragma unroll
+  for (int k = 0; k < 5; k++) pin[k] = make_double2(0.0, 0.0);
+  auto request = [&](int64_t e) {  // inputs of element e -> registers
+    if (e >= a.nel) return;
+    const int64_t ex = e % mx, t = e / mx, ey = t % my, ez = s.els + t / my;
     if (q < 24) {
       const int n = q / 3, d = q % 3;
       const int64_t node = (ex + HDI[n]) + M * ((ey + HDJ[n]) + N * (ez + HDK[n] - s.cks));
-      sh_xc[el][q] = a.coords[3 * node + d];
+      pxc = a.coords[3 * node + d];
     }
-    if (aos) {  // contiguous, 16 bytes per lane (the element block is 16-byte aligned for every stride in use)
+    if (aos) {
       const double *pr = a.gp + (ex + mx * (ey + my * (ez - s.mat_e_ks))) * a.mat_stride + 112;
-      if ((a.mat_stride & 1) == 0) {
+      if (wide) {
         const double2 *src = reinterpret_cast<const double2 *>(pr);
-        double2 *dst = reinterpret_cast<double2 *>(sh_in[el]);
-        for (int k = q; k < 144; k += 32) dst[k] = src[k];
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+          if (q + 32 * k < 144) pin[k] = src[q + 32 * k];
       } else {
-        for (int k = q; k < 288; k += 32) sh_in[el][k] = pr[k];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+          const int i0 = 2 * (q + 32 * k);
+          if (i0 < 288) pin[k] = make_double2(pr[i0], pr[i0 + 1]);
+        }
       }
     }
-  }
-  __syncthreads();
-  if (live) {
-    const double *xc = sh_xc[el];
-    const double *in = sh_in[el];
-    if (q < 24) {
-      double sn[3] = {0.0, 0.0, 0.0};
-      if (aos) {
-        const double dx = fabs(xc[0] - xc[9]), dy = fabs(xc[1] - xc[4]), dz = fabs(xc[2] - xc[14]);
-        const double *gx = in + 72, *gy = in + 144, *gz = in + 216;
-        const double pe = in[q], pn = in[24 + q];
-        const double factor = pe * (1 - pn) / ((1.0 + pn) * (1.0 - 2.0 * pn));
-        const double d11 = factor * 1.0, d12 = factor * (pn / (1 - pn)), d44 = factor * (0.5 * (1 - 2 * pn) / (1 - pn));
-        const double e0 = gx[3 * q], e1 = gy[3 * q + 1], e2 = gz[3 * q + 2];
-        const double e3 = gx[3 * q + 1] + gy[3 * q], e4 = gy[3 * q + 2] + gz[3 * q + 1], e5 = gx[3 * q + 2] + gz[3 * q];
-        const double z0 = d11 * e0 + d12 * e1 + d12 * e2;
-        const double z1 = d12 * e0 + d11 * e1 + d12 * e2;
-        const double z2 = d12 * e0 + d12 * e1 + d11 * e2;
-        const double z3 = d44 * e3, z4 = d44 * e4, z5 = d44 * e5;
-        const int axis = q >> 3;
-        const double side = ((q >> 2) & 1) ? -1.0 : 1.0;
-        double Jp;
-        if (axis == 0)      { sn[0] = z0 * side; sn[1] = z3 * side; sn[2] = z5 * side; Jp = (0.5 * dy) * (0.5 * dz); }
-        else if (axis == 1) { sn[0] = z3 * side; sn[1] = z1 * side; sn[2] = z4 * side; Jp = (0.5 * dx) * (0.5 * dz); }
-        else                { sn[0] = z5 * side; sn[1] = z4 * side; sn[2] = z2 * side; Jp = (0.5 * dx) * (0.5 * dy); }
-        const double fac = 1.0 * Jp;
+  };
+
+  int64_t g = blockIdx.x;
+  if (g < ngroups) request(16 * g + el);
+  for (; g < ngroups; g += gridDim.x) {
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+      const int64_t e = 16 * g + 8 * h + el;
+      const bool live = e < a.nel;
+      if (q < 24) sh_xc[el][q] = pxc;
+      {
+        double2 *dst = reinterpret_cast<double2 *>(sh_in[el]);
 #pragma unroll
-        for (int c = 0; c < 3; c++) sn[c] *= fac;
+        for (int k = 0; k < 5; k++)
+          if (q + 32 * k < 144) dst[q + 32 * k] = pin[k];
       }
-#pragma unroll
-      for (int c = 0; c < 3; c++) sh_t[el][q][c] = sn[c];
-    } else {
-      const int p = q - 24;
-      double u[3] = {0.0, 0.0, 0.0};
-      if (aos) {
-        const double fac = 1.0 * det3_only(c_tab3.G[p], xc);
-        u[0] = fac * in[48 + p];
-        u[1] = fac * in[56 + p];
-        u[2] = fac * in[64 + p];
+      {  // next half-group
+        const int64_t gn = h ? g + gridDim.x : g;
+        if (gn < ngroups) request(16 * gn + (h ? 0 : 8) + el);
       }
+      __syncthreads();
+      if (live) {
+        const double *xc = sh_xc[el];
+        const double *in = sh_in[el];
+        if (q < 24) {
+          double sn[3] = {0.0, 0.0, 0.0};
+          if (aos) {
+            const double dx = fabs(xc[0] - xc[9]), dy = fabs(xc[1] - xc[4]), dz = fabs(xc[2] - xc[14]);
+            const double *gx = in + 72, *gy = in + 144, *gz = in + 216;
+            const double pe = in[q], pn = in[24 + q];
+            const double factor = pe * (1 - pn) / ((1.0 + pn) * (1.0 - 2.0 * pn));
+            const double d11 = factor * 1.0, d12 = factor * (pn / (1 - pn)), d44 = factor * (0.5 * (1 - 2 * pn) / (1 - pn));
+            const double e0 = gx[3 * q], e1 = gy[3 * q + 1], e2 = gz[3 * q + 2];
+            const double e3 = gx[3 * q + 1] + gy[3 * q], e4 = gy[3 * q + 2] + gz[3 * q + 1], e5 = gx[3 * q + 2] + gz[3 * q];
+            const double z0 = d11 * e0 + d12 * e1 + d12 * e2;
+            const double z1 = d12 * e0 + d11 * e1 + d12 * e2;
+            const double z2 = d12 * e0 + d12 * e1 + d11 * e2;
+            const double z3 = d44 * e3, z4 = d44 * e4, z5 = d44 * e5;
+            const int axis = q >> 3;
+            const double side = ((q >> 2) & 1) ? -1.0 : 1.0;
+            double Jp;
+            if (axis == 0)      { sn[0] = z0 * side; sn[1] = z3 * side; sn[2] = z5 * side; Jp = (0.5 * dy) * (0.5 * dz); }
+            else if (axis == 1) { sn[0] = z3 * side; sn[1] = z1 * side; sn[2] = z4 * side; Jp = (0.5 * dx) * (0.5 * dz); }
+            else                { sn[0] = z5 * side; sn[1] = z4 * side; sn[2] = z2 * side; Jp = (0.5 * dx) * (0.5 * dy); }
+            const double fac = 1.0 * Jp;
 #pragma unroll
-      for (int c = 0; c < 3; c++) sh_u[el][p][c] = u[c];
+            for (int c = 0; c < 3; c++) sn[c] *= fac;
+          }
+#pragma unroll
+          for (int c = 0; c < 3; c++) sh_t[el][q][c] = sn[c];
+        } else {
+          const int p = q - 24;
+          double u[3] = {0.0, 0.0, 0.0};
+          if (aos) {
+            const double fac = 1.0 * det3_only(c_tab3.G[p], xc);
+            u[0] = fac * in[48 + p];
+            u[1] = fac * in[56 + p];
+            u[2] = fac * in[64 + p];
+          }
+#pragma unroll
+          for (int c = 0; c < 3; c++) sh_u[el][p][c] = u[c];
+        }
+      }
+      __syncthreads();
+      if (q < 24) {
+        double fe = 0.0, ge = 0.0;
+        if (live) {
+          const int n = q / 3, c = q % 3;
+#pragma unroll
+          for (int p = 0; p < 8; p++) fe += sh_N[p][n] * sh_u[el][p][c];
+#pragma unroll
+          for (int p = 0; p < 24; p++) ge += sh_NF[p][n] * sh_t[el][p][c];
+        }
+        sh_out[q][8 * h + el] = fe + ge;
+      }
     }
-  }
-  __syncthreads();
-  if (live && q < 24) {
-    const int n = q / 3, c = q % 3;
-    double fe = 0.0, ge = 0.0;
-#pragma unroll
-    for (int p = 0; p < 8; p++) fe += sh_N[p][n] * sh_u[el][p][c];
-#pragma unroll
-    for (int p = 0; p < 24; p++) ge += sh_NF[p][n] * sh_t[el][p][c];
-    a.elemF[e * 48 + q] = fe;
-    a.elemF[e * 48 + 24 + q] = ge;
+    __syncthreads();
+    if (tid < 192) {  // 24 lines of 16 elements, 16 bytes per lane
+      const int t = tid >> 3, part = tid & 7;
+      *reinterpret_cast<double2 *>(a.elemF + t * a.nelp + 16 * g + 2 * part) =
+          *reinterpret_cast<const double2 *>(&sh_out[t][2 * part]);
+    }
   }
 }
 
 // ---------------------------------------------------------------------------
 // RHS, pass 2: one thread per node; contributions added in the reference's element
-// order (k -> j -> i), Fe before Ge (S3:787-788); then the Dirichlet value.
+// order (k -> j -> i) (S3: Fe + Ge of an element enter as one term); then the Dirichlet value.
 // ---------------------------------------------------------------------------
 template <int KIND>
 __global__ __launch_bounds__(256) void k_rhs_gather(const Slab s, const RArgs a) {
@@ -790,24 +835,20 @@ __global__ __launch_bounds__(256) void k_rhs_gather(const Slab s, const RArgs a)
         for (int ox = -1; ox <= 0; ox++) {
           const int64_t ex = i + ox, ey = j + oy, ez = k + oz;
           if (ex < 0 || ex >= mx || ey < 0 || ey >= my || ez < s.els || ez >= s.ele) continue;
-          const double *F = a.elemF + (ex + mx * (ey + my * (ez - s.els))) * NFE;
+          const double *F = a.elemF + (ex + mx * (ey + my * (ez - s.els)));
           const int al = hex_idx(-ox, -oy, -oz);
 #pragma unroll
-          for (int c = 0; c < DOF; c++) b[c] = b[c] + F[al * DOF + c];
-          if constexpr (KIND == KIND_ELASTIC) {
-#pragma unroll
-            for (int c = 0; c < DOF; c++) b[c] = b[c] + F[24 + al * DOF + c];
-          }
+          for (int c = 0; c < DOF; c++) b[c] = b[c] + F[(al * DOF + c) * a.nelp];
         }
   } else {
     for (int oy = -1; oy <= 0; oy++)
       for (int ox = -1; ox <= 0; ox++) {
         const int64_t ex = i + ox, ey = j + oy;
         if (ex < 0 || ex >= mx || ey < s.els || ey >= s.ele) continue;
-        const double *F = a.elemF + (ex + mx * (ey - s.els)) * NFE;
+        const double *F = a.elemF + (ex + mx * (ey - s.els));
         const int al = quad_idx(-ox, -oy);
 #pragma unroll
-        for (int c = 0; c < DOF; c++) b[c] = b[c] + F[al * DOF + c];
+        for (int c = 0; c < DOF; c++) b[c] = b[c] + F[(al * DOF + c) * a.nelp];
       }
   }
 
