@@ -217,11 +217,21 @@ int launch_rhs(femasm_plan *p, const femasm_material *mat, int bc, double *out, 
   a.mat_stride = mat ? mat->stride : 0;
   a.bc = bc;
   a.iface = iface;
+  a.bad = p->bad;
   if (do_elem && p->nel > 0) {
     if (KIND == KIND_ELASTIC) {
-      const int64_t ngroups = (p->nel + 15) / 16;
-      hipLaunchKernelGGL(k_rhs_elem_elastic_coop, dim3((unsigned)(ngroups < 2048 ? ngroups : 2048)), dim3(256), 0,
-                         p->stream, p->s, a);
+      // persistent workgroups: exactly one resident set, so that every one walks the same number of groups
+      static int wg_per_cu = 0, ncu = 0;
+      if (!wg_per_cu) {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, p->device));
+        ncu = prop.multiProcessorCount;
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, k_rhs_elem_elastic_coop, 256, 0));
+        if (wg_per_cu < 1) wg_per_cu = 1;
+      }
+      const int64_t ngroups = (p->nel + 15) / 16 / 4 + 1, resident = (int64_t)ncu * wg_per_cu;  // 4 groups per workgroup pass
+      hipLaunchKernelGGL(k_rhs_elem_elastic_coop, dim3((unsigned)(ngroups < resident ? ngroups : resident)), dim3(256),
+                         0, p->stream, p->s, a);
     }
     else
       hipLaunchKernelGGL(k_rhs_elem<KIND>, dim3(nblk(p->nel)), dim3(256), 0, p->stream, p->s, a);
@@ -358,6 +368,8 @@ int femasm_plan_destroy(femasm_plan *p) {
     if (p->bad && hipMemcpy(t, p->bad, sizeof t, hipMemcpyDeviceToHost) == hipSuccess) {
       fprintf(stderr, "[femasm phases] row waves: n=%llu barrier %llu contract %llu stage %llu store %llu | record wave: n=%llu top %llu commit+load %llu build %llu handshakes %llu\n",
               t[8], t[9], t[10], t[11], t[12], t[16], t[17], t[18], t[19], t[20]);
+      fprintf(stderr, "[femasm phases] rhs coop: n=%llu commit %llu request %llu phaseA %llu phaseB %llu\n", t[24], t[25], t[26],
+              t[27], t[28]);
     }
   }
 #endif

@@ -549,6 +549,28 @@ __global__ __launch_bounds__(256, 2) void k_assemble_rows(const Slab s, const KA
 // ---------------------------------------------------------------------------
 // RHS, pass 1: one thread per assembled element -> Fe (and Ge) in the scratch array
 // ---------------------------------------------------------------------------
+#define PH_BUF a.bad
+#if FEMASM_EXP == 3  // phase clocks (profiling build only): PH_ACC(p, id) adds the time since the last mark to phase p
+#define PH_DECL unsigned long long ph_[4] = {0, 0, 0, 0}, ph_n = 0, ph_t = 0
+#define PH_T(id) ph_t = __builtin_readcyclecounter(), ph_n++
+#define PH_ACC(p, id)                                            \
+  do {                                                           \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    ph_[p] += now_ - ph_t;                                       \
+    ph_t = now_;                                                 \
+  } while (0)
+#define PH_FLUSH(base)                                                    \
+  if (lane == 0) {                                                        \
+    atomicAdd(PH_BUF + (base), ph_n);                                      \
+    for (int q_ = 0; q_ < 4; q_++) atomicAdd(PH_BUF + (base) + 1 + q_, ph_[q_]); \
+  }
+#else
+#define PH_DECL
+#define PH_T(id)
+#define PH_ACC(p, id)
+#define PH_FLUSH(base)
+#endif
+
 struct RArgs {
   const double *coords;
   const double *gp;
@@ -561,6 +583,7 @@ struct RArgs {
   int64_t nel;            // assembled elements
   int32_t mat_layout, mat_stride;
   int32_t bc, iface;
+  unsigned long long *bad;  // plan flags / profiling counters
 };
 
 template <int KIND>
@@ -671,38 +694,58 @@ __global__ __launch_bounds__(256) void k_rhs_elem(const Slab s, const RArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// RHS, pass 1 for S3/R3, cooperative streaming form.  A workgroup walks over groups of 16 consecutive
-// elements, 8 at a time with 32 lanes per element; the 2.3 KB of per-element AoS inputs (doubles [112,400) =
-// E_B[24] nu_B[24] fx[8] fy[8] fz[8] gx[72] gy[72] gz[72]) are read as contiguous 16-byte-per-lane runs, one
-// half-group ahead through registers.  Lane q < 24 owns face Gauss point q (traction sigma.n * face Jacobian,
-// S3:568-648), lane q >= 24 owns volume Gauss point q-24 (w*detJ * f, S3:534-545); then lane q < 24 = dof
-// (node q/3, component q%3) sums its 8 + 24 terms in Gauss-point order.  Fe + Ge of the 16 elements leave as 24
-// full 128-byte lines of the component-major element-vector array.
+// RHS, pass 1 for S3/R3, cooperative streaming form.  Every WAVE is autonomous (no workgroup barrier in the
+// loop, so a wave waiting for memory never holds up another): it walks over groups of 16 consecutive elements,
+// two at a time with 32 lanes per element.  The 2.3 KB of per-element AoS inputs (doubles [112,400) =
+// E_B[24] nu_B[24] fx[8] fy[8] fz[8] gx[72] gy[72] gz[72]) are read as contiguous 16-byte-per-lane runs, two
+// element pairs ahead through registers.  Lane q < 24 owns face Gauss point q (traction sigma.n * face
+// Jacobian, S3:568-648), lane q >= 24 owns volume Gauss point q-24 (w*detJ * f, S3:534-545); then lane
+// (n = q/4, r = q%4) sums the Gauss points p = r mod 4 for the three components of node n and the quad combines
+// its four partial sums.  Fe + Ge of the 16 elements leave as 24 full 128-byte lines of the component-major
+// element-vector array.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rhs_elem_elastic_coop(const Slab s, const RArgs a) {
-  __shared__ __attribute__((aligned(16))) double sh_in[8][288];
-  __shared__ double sh_xc[8][24];
-  __shared__ double sh_t[8][24][3];
-  __shared__ double sh_u[8][8][3];
-  __shared__ double sh_N[8][8];
-  __shared__ double sh_NF[24][8];
-  __shared__ __attribute__((aligned(16))) double sh_out[24][16];
-  const int tid = threadIdx.x, el = tid >> 5, q = tid & 31;
+  __shared__ __attribute__((aligned(16))) double sh_in[4][2][288];
+  __shared__ double sh_xc[4][2][24];
+  __shared__ __attribute__((aligned(16))) double sh_w[4][2][32][4];  // 24 face tractions, 8 volume loads
+  __shared__ double sh_C[32][8];                                     // NF[p][n] (p < 24), N[p-24][n]
+  __shared__ double sh_G[8][3][8];
+  __shared__ __attribute__((aligned(16))) double sh_out[4][24][16];
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, el = lane >> 5, q = lane & 31;
   const int64_t M = s.dim[0], N = s.dim[1];
   const int64_t mx = M - 1, my = N - 1;
   const int64_t ngroups = (a.nel + 15) >> 4;
   const bool aos = a.mat_layout == 0;
   const bool wide = (a.mat_stride & 1) == 0;  // element blocks keep the base's 16-byte alignment
-  if (tid < 64) sh_N[tid >> 3][tid & 7] = c_tab3.N[tid >> 3][tid & 7];
-  else sh_NF[(tid - 64) >> 3][tid & 7] = c_tab3.NF[(tid - 64) >> 3][tid & 7];
+  // the reference tables go to LDS: a table read from memory inside the loop would queue behind the prefetch
+  // (loads of one wave return in order)
+  if (tid < 64) sh_C[24 + (tid >> 3)][tid & 7] = c_tab3.N[tid >> 3][tid & 7];
+  else sh_C[(tid - 64) >> 3][tid & 7] = c_tab3.NF[(tid - 64) >> 3][tid & 7];
+  if (tid < 192) (&sh_G[0][0][0])[tid] = (&c_tab3.G[0][0][0])[tid];
+  __syncthreads();
 
-  double2 pin[5];
-  double pxc = 0.0;
+  // two register sets, one per parity of the pair index: what a step commits was requested two steps earlier
+  double2 pins[2][5];
+  double pxcs[2] = {0.0, 0.0};
 #pragma unroll
-  for (int k = 0; k < 5; k++) pin[k] = make_double2(0.0, 0.0);
-  auto request = [&](int64_t e) {  // inputs of element e -> registers
+  for (int h = 0; h < 2; h++)
+#pragma unroll
+    for (int k = 0; k < 5; k++) pins[h][k] = make_double2(0.0, 0.0);
+  auto request = [&](int64_t e, double2 *pin, double &pxc) {  // inputs of element e -> registers
     if (e >= a.nel) return;
-    const int64_t ex = e % mx, t = e / mx, ey = t % my, ez = s.els + t / my;
+    int64_t ex, ey, ez;
+    if (a.nel < (int64_t)1 << 31) {  // 32-bit divisions: a 64-bit one costs more than the rest of the step
+      const uint32_t e32 = (uint32_t)e, mx32 = (uint32_t)mx, my32 = (uint32_t)my;
+      const uint32_t t = e32 / mx32, u = t / my32;
+      ex = e32 - t * mx32;
+      ey = t - u * my32;
+      ez = s.els + u;
+    } else {
+      const int64_t t = e / mx;
+      ex = e % mx;
+      ey = t % my;
+      ez = s.els + t / my;
+    }
     if (q < 24) {
       const int n = q / 3, d = q % 3;
       const int64_t node = (ex + HDI[n]) + M * ((ey + HDJ[n]) + N * (ez + HDK[n] - s.cks));
@@ -724,88 +767,122 @@ __global__ __launch_bounds__(256) void k_rhs_elem_elastic_coop(const Slab s, con
       }
     }
   };
+  auto wave_sync = [&]() {  // LDS written by this wave, read by other lanes of this wave: in order in hardware
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  };
 
-  int64_t g = blockIdx.x;
-  if (g < ngroups) request(16 * g + el);
-  for (; g < ngroups; g += gridDim.x) {
-#pragma unroll 1
-    for (int h = 0; h < 2; h++) {
-      const int64_t e = 16 * g + 8 * h + el;
-      const bool live = e < a.nel;
-      if (q < 24) sh_xc[el][q] = pxc;
-      {
-        double2 *dst = reinterpret_cast<double2 *>(sh_in[el]);
-#pragma unroll
-        for (int k = 0; k < 5; k++)
-          if (q + 32 * k < 144) dst[q + 32 * k] = pin[k];
-      }
-      {  // next half-group
-        const int64_t gn = h ? g + gridDim.x : g;
-        if (gn < ngroups) request(16 * gn + (h ? 0 : 8) + el);
-      }
-      __syncthreads();
-      if (live) {
-        const double *xc = sh_xc[el];
-        const double *in = sh_in[el];
-        if (q < 24) {
-          double sn[3] = {0.0, 0.0, 0.0};
-          if (aos) {
-            const double dx = fabs(xc[0] - xc[9]), dy = fabs(xc[1] - xc[4]), dz = fabs(xc[2] - xc[14]);
-            const double *gx = in + 72, *gy = in + 144, *gz = in + 216;
-            const double pe = in[q], pn = in[24 + q];
-            const double factor = pe * (1 - pn) / ((1.0 + pn) * (1.0 - 2.0 * pn));
-            const double d11 = factor * 1.0, d12 = factor * (pn / (1 - pn)), d44 = factor * (0.5 * (1 - 2 * pn) / (1 - pn));
-            const double e0 = gx[3 * q], e1 = gy[3 * q + 1], e2 = gz[3 * q + 2];
-            const double e3 = gx[3 * q + 1] + gy[3 * q], e4 = gy[3 * q + 2] + gz[3 * q + 1], e5 = gx[3 * q + 2] + gz[3 * q];
-            const double z0 = d11 * e0 + d12 * e1 + d12 * e2;
-            const double z1 = d12 * e0 + d11 * e1 + d12 * e2;
-            const double z2 = d12 * e0 + d12 * e1 + d11 * e2;
-            const double z3 = d44 * e3, z4 = d44 * e4, z5 = d44 * e5;
-            const int axis = q >> 3;
-            const double side = ((q >> 2) & 1) ? -1.0 : 1.0;
-            double Jp;
-            if (axis == 0)      { sn[0] = z0 * side; sn[1] = z3 * side; sn[2] = z5 * side; Jp = (0.5 * dy) * (0.5 * dz); }
-            else if (axis == 1) { sn[0] = z3 * side; sn[1] = z1 * side; sn[2] = z4 * side; Jp = (0.5 * dx) * (0.5 * dz); }
-            else                { sn[0] = z5 * side; sn[1] = z4 * side; sn[2] = z2 * side; Jp = (0.5 * dx) * (0.5 * dy); }
-            const double fac = 1.0 * Jp;
-#pragma unroll
-            for (int c = 0; c < 3; c++) sn[c] *= fac;
-          }
-#pragma unroll
-          for (int c = 0; c < 3; c++) sh_t[el][q][c] = sn[c];
-        } else {
-          const int p = q - 24;
-          double u[3] = {0.0, 0.0, 0.0};
-          if (aos) {
-            const double fac = 1.0 * det3_only(c_tab3.G[p], xc);
-            u[0] = fac * in[48 + p];
-            u[1] = fac * in[56 + p];
-            u[2] = fac * in[64 + p];
-          }
-#pragma unroll
-          for (int c = 0; c < 3; c++) sh_u[el][p][c] = u[c];
-        }
-      }
-      __syncthreads();
-      if (q < 24) {
-        double fe = 0.0, ge = 0.0;
-        if (live) {
-          const int n = q / 3, c = q % 3;
-#pragma unroll
-          for (int p = 0; p < 8; p++) fe += sh_N[p][n] * sh_u[el][p][c];
-#pragma unroll
-          for (int p = 0; p < 24; p++) ge += sh_NF[p][n] * sh_t[el][p][c];
-        }
-        sh_out[q][8 * h + el] = fe + ge;
-      }
-    }
-    __syncthreads();
-    if (tid < 192) {  // 24 lines of 16 elements, 16 bytes per lane
-      const int t = tid >> 3, part = tid & 7;
-      *reinterpret_cast<double2 *>(a.elemF + t * a.nelp + 16 * g + 2 * part) =
-          *reinterpret_cast<const double2 *>(&sh_out[t][2 * part]);
-    }
+  const int64_t gstride = (int64_t)gridDim.x * 4;
+  int64_t g = (int64_t)blockIdx.x * 4 + w;
+  if (g < ngroups) {
+    request(16 * g + el, pins[0], pxcs[0]);
+    request(16 * g + 2 + el, pins[1], pxcs[1]);
   }
+  PH_DECL;
+  for (; g < ngroups; g += gstride) {
+#pragma unroll 1
+    for (int it2 = 0; it2 < 4; it2++) {
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int it = 2 * it2 + h;  // element pair of the group
+        double2 *pin = pins[h];
+        double &pxc = pxcs[h];
+        const int64_t e = 16 * g + 2 * it + el;
+        const bool live = e < a.nel;
+        PH_T(0);
+        if (q < 24) sh_xc[w][el][q] = pxc;
+        {
+          double2 *dst = reinterpret_cast<double2 *>(sh_in[w][el]);
+#pragma unroll
+          for (int k = 0; k < 5; k++)
+            if (q + 32 * k < 144) dst[q + 32 * k] = pin[k];
+        }
+        PH_ACC(0, 1);
+        {  // two pairs ahead: same group, or the first pairs of this wave's next group
+          const int64_t en = (it < 6) ? 16 * g + 2 * (it + 2) : 16 * (g + gstride) + 2 * (it - 6);
+          if (en < 16 * ngroups) request(en + el, pin, pxc);
+        }
+        PH_ACC(1, 2);
+        wave_sync();
+        if (live) {
+          const double *xc = sh_xc[w][el];
+          const double *in = sh_in[w][el];
+          if (q < 24) {
+            double sn[3] = {0.0, 0.0, 0.0};
+            if (aos) {
+              const double dx = fabs(xc[0] - xc[9]), dy = fabs(xc[1] - xc[4]), dz = fabs(xc[2] - xc[14]);
+              const double *gx = in + 72, *gy = in + 144, *gz = in + 216;
+              const double pe = in[q], pn = in[24 + q];
+              const double factor = pe * (1 - pn) / ((1.0 + pn) * (1.0 - 2.0 * pn));
+              const double d11 = factor * 1.0, d12 = factor * (pn / (1 - pn)), d44 = factor * (0.5 * (1 - 2 * pn) / (1 - pn));
+              const double e0 = gx[3 * q], e1 = gy[3 * q + 1], e2 = gz[3 * q + 2];
+              const double e3 = gx[3 * q + 1] + gy[3 * q], e4 = gy[3 * q + 2] + gz[3 * q + 1], e5 = gx[3 * q + 2] + gz[3 * q];
+              const double z0 = d11 * e0 + d12 * e1 + d12 * e2;
+              const double z1 = d12 * e0 + d11 * e1 + d12 * e2;
+              const double z2 = d12 * e0 + d12 * e1 + d11 * e2;
+              const double z3 = d44 * e3, z4 = d44 * e4, z5 = d44 * e5;
+              const int axis = q >> 3;
+              const double side = ((q >> 2) & 1) ? -1.0 : 1.0;
+              double Jp;
+              if (axis == 0)      { sn[0] = z0 * side; sn[1] = z3 * side; sn[2] = z5 * side; Jp = (0.5 * dy) * (0.5 * dz); }
+              else if (axis == 1) { sn[0] = z3 * side; sn[1] = z1 * side; sn[2] = z4 * side; Jp = (0.5 * dx) * (0.5 * dz); }
+              else                { sn[0] = z5 * side; sn[1] = z4 * side; sn[2] = z2 * side; Jp = (0.5 * dx) * (0.5 * dy); }
+              const double fac = 1.0 * Jp;
+#pragma unroll
+              for (int c = 0; c < 3; c++) sn[c] *= fac;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) sh_w[w][el][q][c] = sn[c];
+          } else {
+            const int p = q - 24;
+            double u[3] = {0.0, 0.0, 0.0};
+            if (aos) {
+              const double fac = 1.0 * det3_only(sh_G[p], xc);
+              u[0] = fac * in[48 + p];
+              u[1] = fac * in[56 + p];
+              u[2] = fac * in[64 + p];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) sh_w[w][el][q][c] = u[c];
+          }
+        }
+        PH_ACC(2, 3);
+        wave_sync();
+        {
+          const int n = q >> 2, r = q & 3;
+          double o[3] = {0.0, 0.0, 0.0};
+          if (live) {
+#pragma unroll
+            for (int pp = 0; pp < 8; pp++) {
+              const int p = r + 4 * pp;
+              const double cf = sh_C[p][n];
+              const double2 w01 = *reinterpret_cast<const double2 *>(&sh_w[w][el][p][0]);
+              const double w2 = sh_w[w][el][p][2];
+              o[0] = fma(cf, w01.x, o[0]);
+              o[1] = fma(cf, w01.y, o[1]);
+              o[2] = fma(cf, w2, o[2]);
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            o[c] += __shfl_xor(o[c], 1);
+            o[c] += __shfl_xor(o[c], 2);
+          }
+          if (r < 3) sh_out[w][3 * n + r][2 * it + el] = o[r];
+        }
+        PH_ACC(3, 4);
+        wave_sync();  // sh_w / sh_in / sh_xc are rewritten by the next pair
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {  // 24 lines of 16 elements, 16 bytes per lane
+      const int idx = lane + 64 * k, t = idx >> 3, part = idx & 7;
+      *reinterpret_cast<double2 *>(a.elemF + t * a.nelp + 16 * g + 2 * part) =
+          *reinterpret_cast<const double2 *>(&sh_out[w][t][2 * part]);
+    }
+    wave_sync();
+  }
+  PH_FLUSH(24);
 }
 
 // ---------------------------------------------------------------------------

@@ -401,26 +401,6 @@ struct RowSweep {
 };
 constexpr int RS_ZC = 16;  // node layers per workgroup
 
-#if FEMASM_EXP == 3  // phase clocks (profiling build only): PH_ACC(p, id) adds the time since the last mark to phase p
-#define PH_DECL unsigned long long ph_[4] = {0, 0, 0, 0}, ph_n = 0, ph_t = 0
-#define PH_T(id) ph_t = __builtin_readcyclecounter(), ph_n++
-#define PH_ACC(p, id)                                            \
-  do {                                                           \
-    const unsigned long long now_ = __builtin_readcyclecounter(); \
-    ph_[p] += now_ - ph_t;                                       \
-    ph_t = now_;                                                 \
-  } while (0)
-#define PH_FLUSH(base)                                                    \
-  if (lane == 0) {                                                        \
-    atomicAdd(a.bad + (base), ph_n);                                      \
-    for (int q_ = 0; q_ < 4; q_++) atomicAdd(a.bad + (base) + 1 + q_, ph_[q_]); \
-  }
-#else
-#define PH_DECL
-#define PH_T(id)
-#define PH_ACC(p, id)
-#define PH_FLUSH(base)
-#endif
 
 // contributions of the four elements of one element layer to row C of the lane's node.
 // AS = 1: the node is on the top face of these elements (layer kn-1), AS = 0: on their bottom face (layer kn).

@@ -5,13 +5,14 @@ R=$GRAFT_REPO_ROOT
 cd /tmp
 run() { # name counters...
   name=$1; shift
-  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_$name -- python3 $R/bench.py --steps 3 --warmup 1 --k-only --no-cpu-baseline $EXTRA > $R/gpurun_out/pmc_$name.json 2> $R/gpurun_out/pmc_$name.err || { echo "pass $name failed"; tail -5 $R/gpurun_out/pmc_$name.err; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_$name -- python3 $R/bench.py --steps 3 --warmup 1 $KONLY --no-cpu-baseline $EXTRA > $R/gpurun_out/pmc_$name.json 2> $R/gpurun_out/pmc_$name.err || { echo "pass $name failed"; tail -5 $R/gpurun_out/pmc_$name.err; exit 1; }
   python3 - $R/gpurun_out/pmc_$name <<'PY'
 import csv,glob,sys,collections
 d=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1]+'/**/*counter_collection.csv',recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'k_assemble' in r['Kernel_Name'] or 'k_bc_rows' in r['Kernel_Name']:
+        import os
+        if os.environ.get('KPAT','k_assemble') in r['Kernel_Name']:
             d[r['Kernel_Name'][:60]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k,v in d.items():
     print(k)

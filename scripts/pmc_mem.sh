@@ -3,5 +3,5 @@
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 source <(sed -n '/^run()/,/^}/p' $R/scripts/pmc_k.sh)
-cd /tmp
+cd /tmp; : ${KONLY=--k-only}
 run wr WRITE_SIZE && run rd FETCH_SIZE
