@@ -85,6 +85,23 @@ def cpu_baseline(workload):
             "seconds": round(dt, 3)}
 
 
+def measured_traffic(wl, nel, world, args):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*/traffic.json,
+    FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs of this same command and corrected
+    as MI355X_MICROARCH.md prescribes).  None when this exact configuration was not profiled."""
+    if world != 1 or args.perturb or args.uniform_material or args.k_only or args.fast_level != 2:
+        return None
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for rnd in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        f = os.path.join(pdir, rnd, "traffic.json")
+        if os.path.exists(f):
+            for rec in json.load(open(f)).get("kernels", []):
+                if rec.get("workload") == wl and rec.get("nel") == nel:
+                    best = rec.get("hbm_bytes_per_launch")
+    return best
+
+
 def main():
     args = parse()
     import torch
@@ -160,7 +177,7 @@ def main():
         recv = torch.empty(max(rc, 1), dtype=torch.float64, device=dev)
         plan.interface_set_buffers(send if sc else None, recv if rc else None)
 
-    k_ms = []
+    k_ms, main_ms = [], []
 
     def step(collect):
         st = plan.assemble_system(vals, b, material=material, stride=stride, bc=bc, E=E, nu=nu, e_ks=els,
@@ -170,6 +187,7 @@ def main():
             plan.interface_apply(vals, b, bc=bc)
         if collect:
             k_ms.append(st.ms_kernel_K)
+            main_ms.append(st.ms_kernel_main)
         return st
 
     for _ in range(args.warmup):
@@ -197,18 +215,17 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
-        k_avg_ms = sum(k_ms) / len(k_ms)
-        achieved = st.bytes_K / (k_avg_ms * 1e-3) / 1e9
+        k_avg_ms = sum(k_ms) / len(k_ms)        # all stiffness kernels (interior + Dirichlet shell rows)
+        main_avg_ms = sum(main_ms) / len(main_ms)  # the dominant kernel alone, HIP events on its stream
+        achieved = st.bytes_main / (main_avg_ms * 1e-3) / 1e9
         level = plan.fast_path()
         if wl == "elastic2d":
             kernel = "k_assemble_rows<PLANE_STRAIN2D>"
         else:
             kname = "ELASTIC3D" if wl == "elastic3d" else "POISSON3D"
-            if level == 0:
-                kernel = f"k_assemble_sweep<{kname}>"
-            else:
-                box = "true" if (level == 2 and wl == "elastic3d") else "false"
-                kernel = f"k_assemble_sweep_affine<{kname}, box={box}>"
+            fast = (level == 2) if wl == "elastic3d" else (level >= 1)
+            kernel = f"k_assemble_rowsweep<{kname}>" if fast else f"k_assemble_sweep<{kname}>"
+        traffic = measured_traffic(wl, nel, world, args)
         out = {
             "metric": "global assembly elements/sec + achieved HBM GB/s fraction",
             "value": nel_total / (dt / args.steps),
@@ -240,10 +257,11 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "algorithmic_bytes_per_launch": st.bytes_K,
-                "avg_launch_ms": k_avg_ms,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": st.bytes_main,
+                "avg_launch_ms": main_avg_ms,
             },
+            "k_ms": k_avg_ms,
             "rhs_ms": st.ms_kernel_rhs,
         }
         if world == 1 and not args.no_cpu_baseline:

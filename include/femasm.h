@@ -86,6 +86,8 @@ typedef struct {
   double  bytes_system;    /* algorithmic bytes of the full system                    */
   int64_t nel, nrows, nnz; /* local (slab) sizes                                      */
   int64_t bad_detJ;        /* Gauss points with det(J) <= 0 or NaN                    */
+  double  ms_kernel_main;  /* the dominant stiffness kernel alone (interior rows in 3-D), HIP events */
+  double  bytes_main;      /* its algorithmic bytes: values stored + coordinates and E,nu read once   */
 } femasm_stats;
 
 typedef struct femasm_plan femasm_plan;

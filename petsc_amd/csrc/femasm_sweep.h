@@ -599,6 +599,7 @@ __global__ __launch_bounds__(256, 2) void k_assemble_rowsweep(const Slab s, cons
   }
 
   // ------------------------------- record wave -------------------------------
+  __builtin_amdgcn_s_setprio(3);  // its few memory instructions should not queue behind the row waves' stores
   const bool aos = HASMAT && a.mat_layout == 0;
   auto load_layer = [&](int64_t gk, double (*cr)[3], int ln) {  // node layer gk of the halo'd tile -> registers
     gk = gk < s.cks ? s.cks : (gk > a.cke - 1 ? a.cke - 1 : gk);
@@ -611,8 +612,11 @@ __global__ __launch_bounds__(256, 2) void k_assemble_rowsweep(const Slab s, cons
         gi = gi < 0 ? 0 : (gi > M - 1 ? M - 1 : gi);
         gj = gj < 0 ? 0 : (gj > N - 1 ? N - 1 : gj);
         const double *src = a.coords + 3 * (gi + M * (gj + N * (gk - s.cks)));
-#pragma unroll
-        for (int d = 0; d < 3; d++) cr[ps][d] = src[d];
+        struct __attribute__((packed, aligned(8))) P2 { double x, y; };  // 16-byte load at 8-byte alignment
+        const P2 xy = *reinterpret_cast<const P2 *>(src);
+        cr[ps][0] = xy.x;
+        cr[ps][1] = xy.y;
+        cr[ps][2] = src[2];
       }
     }
   };
@@ -715,6 +719,18 @@ __global__ __launch_bounds__(256, 2) void k_assemble_rowsweep(const Slab s, cons
         }
       } else {  // Poisson: any parallelepiped
         if (!affine) atomicAdd(a.bad + 1, 1ULL);
+        if (J[0][1] == 0.0 && J[0][2] == 0.0 && J[1][0] == 0.0 && J[1][2] == 0.0 && J[2][0] == 0.0 && J[2][1] == 0.0) {
+          // axis-aligned box: iJ = diag(1/J_ii), C = detJ diag(1/J_ii^2); same operations as the general branch
+          // below with the zero terms dropped, so both give the same bits
+          const double wJ = 1.0 * (J[0][0] * J[1][1] * J[2][2]);
+          if (!(wJ > 0.0)) atomicAdd(a.bad, 1ULL);
+          const double t17 = 1.0 / (J[0][0] * J[1][1] * J[2][2]);
+          const double i0 = (J[1][1] * J[2][2]) * t17, i1 = (J[0][0] * J[2][2]) * t17, i2 = (J[0][0] * J[1][1]) * t17;
+          dst[0] = make_double2((i0 * i0) * wJ, 0.0);
+          dst[NS] = make_double2(0.0, (i1 * i1) * wJ);
+          dst[2 * NS] = make_double2(0.0, (i2 * i2) * wJ);
+          return;
+        }
         double iJ[3][3];
         const double t4 = J[2][0] * J[0][1], t6 = J[2][0] * J[0][2], t8 = J[1][0] * J[0][1];
         const double t10 = J[1][0] * J[0][2], t12 = J[0][0] * J[1][1], t14 = J[0][0] * J[1][2];
@@ -822,30 +838,38 @@ __global__ __launch_bounds__(256, 2) void k_assemble_rowsweep(const Slab s, cons
 }
 
 // ---------------------------------------------------------------------------
-// Dirichlet rows (A10/A11): one thread per node of the processed layers; non-Dirichlet nodes exit.
+// Dirichlet rows (A10/A11): one workgroup per x-row of nodes (j,k), one wave per Dirichlet node at a time; the
+// lanes write the node's dof rows (contiguous in the CSR array) as consecutive values.  Rows that are not on a
+// y/z face only have their two end nodes to do.
 // Row = zeros with the diagonal 1 (Poisson: number of assembled elements sharing the node);
 // interface pass: zero rows (the receiver ignores them).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_bc_rows(const Slab s, const KArgs a) {
   const int64_t M = s.dim[0], N = s.dim[1];
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= M) return;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int64_t j, k;
   if (s.nsd == 3) { j = blockIdx.y; k = a.s0 + blockIdx.z; } else { j = a.s0 + blockIdx.y; k = 0; }
-  if (!is_bc_node(s, a.bc, i, j, k)) return;
-  double diag = a.iface ? 0.0 : 1.0;
-  if (a.bc == BC_POISSON) {
-    const int vx = (i > 0) + (i < M - 1), vy = (j > 0) + (j < N - 1);
-    const int vz = (k - 1 >= s.els && k - 1 < s.ele) + (k >= s.els && k < s.ele);
-    diag = (double)(vx * vy * vz);
-  }
-  const int cx = span1(i, M), cy = span1(j, N), cz = span1(k, s.dim[2]);
-  const int cnt = cx * cy * cz * s.dof;
-  // position of the node itself among its neighbours
-  const int self = (((s.nsd == 3 ? (k > 0) : 0) * cy + (j > 0)) * cx + (i > 0)) * s.dof;
-  for (int c = 0; c < s.dof; c++) {
-    double *row = a.out + (row_start(s, i, j, k, c) - a.base_off);
-    for (int t = 0; t < cnt; t++) row[t] = (t == self + c) ? diag : 0.0;
+  const bool full = (M < 3) || is_bc_node(s, a.bc, 1, j, k);  // is an x-interior node of this row Dirichlet?
+  const int64_t istep = full ? 4 : M;
+  for (int64_t i = full ? w : (w == 0 ? 0 : ((w == 1 && M > 1) ? M - 1 : M)); i < M; i += istep) {
+    if (!is_bc_node(s, a.bc, i, j, k)) continue;
+    double diag = a.iface ? 0.0 : 1.0;
+    if (a.bc == BC_POISSON) {
+      const int vx = (i > 0) + (i < M - 1), vy = (j > 0) + (j < N - 1);
+      const int vz = (k - 1 >= s.els && k - 1 < s.ele) + (k >= s.els && k < s.ele);
+      diag = (double)(vx * vy * vz);
+    }
+    const int cx = span1(i, M), cy = span1(j, N), cz = span1(k, s.dim[2]);
+    const int cnt = cx * cy * cz * s.dof;
+    // position of the node itself among its neighbours
+    const int self = (((s.nsd == 3 ? (k > 0) : 0) * cy + (j > 0)) * cx + (i > 0)) * s.dof;
+    double *blk = a.out + (row_start(s, i, j, k, 0) - a.base_off);
+    int c = 0, r = lane;  // value t = c * cnt + r of the node's block
+    for (int t = lane; t < s.dof * cnt; t += 64) {
+      while (r >= cnt) { r -= cnt; c++; }
+      blk[t] = (r == self + c) ? diag : 0.0;
+      r += 64;
+    }
   }
 }
 

@@ -62,7 +62,8 @@ class BC(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("ms_total", C.c_double), ("ms_kernel_K", C.c_double), ("ms_kernel_rhs", C.c_double),
                 ("ms_staging", C.c_double), ("bytes_K", C.c_double), ("bytes_system", C.c_double),
-                ("nel", C.c_int64), ("nrows", C.c_int64), ("nnz", C.c_int64), ("bad_detJ", C.c_int64)]
+                ("nel", C.c_int64), ("nrows", C.c_int64), ("nnz", C.c_int64), ("bad_detJ", C.c_int64),
+                ("ms_kernel_main", C.c_double), ("bytes_main", C.c_double)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
