@@ -51,7 +51,7 @@ def cpu_baseline(workload):
     import numpy as np
     from oracle import oracle as O
     if workload == "elastic3d":
-        n = 32
+        n = 64
         M = n + 1
         coords = O.uniform_coords(3, M, M, M)
         props = O.props_s3(n, n, n, coords)
@@ -60,18 +60,18 @@ def cpu_baseline(workload):
         K, b = O.assemble_elastic3d(M, M, M, coords, props, rp, ci)
         O.bc_s3(M, M, M, coords, rp, ci, K, b)
         dt = time.perf_counter() - t0
-        nel, sample = n ** 3, "32^3 sub-mesh of the 128^3 workload (K + b + BC), scaled per element"
+        nel, sample = n ** 3, "64^3 sub-mesh of the 128^3 workload (K + b + BC), scaled per element"
     elif workload == "poisson3d":
-        n = 64
+        n = 160
         M = n + 1
         coords = O.uniform_coords(3, M, M, M)
         rp, ci = O.pattern(3, 1, M, M, M)
         t0 = time.perf_counter()
         O.assemble_poisson3d(M, M, M, coords, rp, ci)
         dt = time.perf_counter() - t0
-        nel, sample = n ** 3, "64^3 sub-mesh (K + b with in-loop BC)"
+        nel, sample = n ** 3, "160^3 sub-mesh (K + b with in-loop BC)"
     else:
-        n = 1024
+        n = 2560
         M = n + 1
         coords = O.uniform_coords(2, M, M)
         props = O.props_e2(n, n, coords)
@@ -80,7 +80,7 @@ def cpu_baseline(workload):
         K, b = O.assemble_elastic2d(M, M, coords, props, rp, ci)
         O.bc_e2(M, M, rp, ci, K, b)
         dt = time.perf_counter() - t0
-        nel, sample = n * n, "1024^2 sub-mesh (K + b + BC)"
+        nel, sample = n * n, "2560^2 sub-mesh (K + b + BC)"
     return {"value": nel / dt, "unit": "elements/s", "cores": 1, "kind": "port", "sample": sample,
             "seconds": round(dt, 3)}
 
