@@ -180,10 +180,16 @@ def main():
     k_ms, main_ms = [], []
 
     def step(collect):
+        reqs = None
+        if world > 1:
+            # the rows owed to the rank below first, so that their transfer overlaps the bulk of the assembly
+            plan.assemble_interface(material=material, stride=stride, bc=bc, E=E, nu=nu, e_ks=els)
+            reqs = slab.exchange_interface_start(send if rank > 0 else None, recv if rank < world - 1 else None,
+                                                 rank, world)
         st = plan.assemble_system(vals, b, material=material, stride=stride, bc=bc, E=E, nu=nu, e_ks=els,
                                   want_stats=True)
         if world > 1:
-            slab.exchange_interface(send if rank > 0 else None, recv if rank < world - 1 else None, rank, world)
+            slab.exchange_interface_finish(reqs)
             plan.interface_apply(vals, b, bc=bc)
         if collect:
             k_ms.append(st.ms_kernel_K)

@@ -148,6 +148,11 @@ int femasm_interface_buffers(femasm_plan *plan, double **send_buf, int64_t *send
 /* Use caller-owned DEVICE buffers (e.g. torch / PETSc device vectors registered with RCCL)
  * of at least send_count / recv_count doubles instead of the plan's own; NULL keeps it. */
 int femasm_interface_set_buffers(femasm_plan *plan, double *send_buf, double *recv_buf);
+/* Optional first half of a split call, for overlapping the exchange with the bulk of the work: computes ONLY
+ * the partial rows owed to the rank below (the send buffer) and returns without waiting, so that the caller can
+ * start its send on the plan's stream and then call femasm_assemble_system, which skips that part once.  Device
+ * material pointers only.  No counterpart in the reference (MatAssemblyBegin/End P3:345-346 is the closest). */
+int femasm_assemble_interface(femasm_plan *plan, const femasm_material *material, const femasm_bc *bc);
 /* own + received, fixed order (deterministic); Dirichlet rows are left untouched. */
 int femasm_interface_apply(femasm_plan *plan, const femasm_bc *bc, double *csr_values, double *b);
 

@@ -83,6 +83,7 @@ struct femasm_plan {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool iface_done = false;             // femasm_assemble_interface already filled the send buffer for the next call
   bool time_main = false;              // record ev[4], ev[5] around the dominant K kernel of the main pass
   double bytes_main = 0.0;             // its algorithmic bytes
 
@@ -220,9 +221,11 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
 
 template <int KIND>
 int launch_rhs(femasm_plan *p, const femasm_material *mat, int bc, double *out, int64_t s0, int64_t s1, int iface,
-               bool do_elem) {
+               bool do_elem, const Slab *slab = nullptr, int64_t nel = -1) {
   using T = Traits<KIND>;
   if (s1 <= s0) return 0;
+  const Slab &sl = slab ? *slab : p->s;  // element layers [els, ele) to integrate / to gather from
+  if (nel < 0) nel = p->nel;
   RArgs a{};
   a.coords = p->coords;
   a.gp = (mat && mat->layout == FEMASM_MAT_AOS) ? (p->stage_gp ? p->stage_gp : mat->gp) : nullptr;
@@ -231,14 +234,14 @@ int launch_rhs(femasm_plan *p, const femasm_material *mat, int bc, double *out, 
   a.cke = p->cke;
   a.s0 = s0;
   a.s1 = s1;
-  a.nel = p->nel;
+  a.nel = nel;
   a.nelp = (p->nel + 15) & ~(int64_t)15;
   a.mat_layout = mat ? mat->layout : FEMASM_MAT_UNIFORM;
   a.mat_stride = mat ? mat->stride : 0;
   a.bc = bc;
   a.iface = iface;
   a.bad = p->bad;
-  if (do_elem && p->nel > 0) {
+  if (do_elem && nel > 0) {
     if (KIND == KIND_ELASTIC) {
       // persistent workgroups: exactly one resident set, so that every one walks the same number of groups
       static int wg_per_cu = 0, ncu = 0;
@@ -249,17 +252,17 @@ int launch_rhs(femasm_plan *p, const femasm_material *mat, int bc, double *out, 
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, k_rhs_elem_elastic_coop, 256, 0));
         if (wg_per_cu < 1) wg_per_cu = 1;
       }
-      const int64_t ngroups = (p->nel + 15) / 16 / 4 + 1, resident = (int64_t)ncu * wg_per_cu;  // 4 groups per workgroup pass
+      const int64_t ngroups = (nel + 15) / 16 / 4 + 1, resident = (int64_t)ncu * wg_per_cu;  // 4 groups per workgroup pass
       hipLaunchKernelGGL(k_rhs_elem_elastic_coop, dim3((unsigned)(ngroups < resident ? ngroups : resident)), dim3(256),
-                         0, p->stream, p->s, a);
+                         0, p->stream, sl, a);
     }
     else
-      hipLaunchKernelGGL(k_rhs_elem<KIND>, dim3(nblk(p->nel)), dim3(256), 0, p->stream, p->s, a);
+      hipLaunchKernelGGL(k_rhs_elem<KIND>, dim3(nblk(nel)), dim3(256), 0, p->stream, sl, a);
     HIPCHK(hipGetLastError());
   }
   const dim3 ggrid = (T::NSD == 3) ? dim3(nblk(p->s.dim[0]), (unsigned)p->s.dim[1], (unsigned)(s1 - s0))
                                    : dim3(nblk(p->s.dim[0]), (unsigned)(s1 - s0), 1);
-  hipLaunchKernelGGL(k_rhs_gather<KIND>, ggrid, dim3(256), 0, p->stream, p->s, a);
+  hipLaunchKernelGGL(k_rhs_gather<KIND>, ggrid, dim3(256), 0, p->stream, sl, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -529,7 +532,7 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
       case KIND_ELASTIC: r = launch_K<KIND_ELASTIC>(p, &mloc, bc, d_vals, s.ks, s.ke, 0); break;
     }
     if (r) return r;
-    if (s.ks > 0) {  // partial rows of node layer ks-1, owed to the rank below
+    if (s.ks > 0 && !p->iface_done) {  // partial rows of node layer ks-1, owed to the rank below
       switch (p->kind) {
         case KIND_POISSON: r = launch_K<KIND_POISSON>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1); break;
         case KIND_PLANE:   r = launch_K<KIND_PLANE>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1); break;
@@ -555,7 +558,7 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
       case KIND_ELASTIC: rc = launch_rhs<KIND_ELASTIC>(p, &mloc, bc, d_b, s.ks, s.ke, 0, true); break;
     }
     if (rc) return rc;
-    if (s.ks > 0) {
+    if (s.ks > 0 && !p->iface_done) {
       double *sb = p->send + p->send_nnz;
       switch (p->kind) {
         case KIND_POISSON: rc = launch_rhs<KIND_POISSON>(p, &mloc, bc, sb, s.ks - 1, s.ks, 1, false); break;
@@ -622,6 +625,7 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
                           ((aos && p->kind == KIND_ELASTIC) ? 8.0 * 264 * p->nel : 0.0);
     stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   }
+  p->iface_done = false;
   if (bad) return fail(FEMASM_ERR_GEOMETRY, "%llu Gauss points with non-positive or NaN det(J)", bad);
   return FEMASM_OK;
 }
@@ -636,6 +640,71 @@ int femasm_plan_set_fast_path(femasm_plan *p, int level) {
 int femasm_plan_get_fast_path(femasm_plan *p, int *level) {
   if (!p || !level) return fail(FEMASM_ERR_ARG, "null argument");
   *level = p->fast_level;
+  return FEMASM_OK;
+}
+
+int femasm_assemble_interface(femasm_plan *p, const femasm_material *mat, const femasm_bc *bcs) {
+  if (!p) return fail(FEMASM_ERR_ARG, "null plan");
+  HIPCHK(hipSetDevice(p->device));
+  const int bc = bcs ? bcs->kind : FEMASM_BC_NONE;
+  if (bc < 0 || bc > 3) return fail(FEMASM_ERR_ARG, "unknown bc kind %d", bc);
+  if ((bc == FEMASM_BC_POISSON_INLOOP && p->kind != KIND_POISSON) ||
+      (bc == FEMASM_BC_E2_COMPRESSION && p->kind != KIND_PLANE) ||
+      (bc == FEMASM_BC_S3_ALLFACES_EXACT && p->kind != KIND_ELASTIC))
+    return fail(FEMASM_ERR_ARG, "bc kind %d does not belong to problem kind %d", bc, p->kind);
+  femasm_material mloc{};
+  if (p->kind != KIND_POISSON) {
+    if (!mat) return fail(FEMASM_ERR_ARG, "material is required for elastic problems");
+    mloc = *mat;
+    if (mloc.layout == FEMASM_MAT_AOS) {
+      const int need = (p->kind == KIND_PLANE) ? 24 : 400;
+      if (!mloc.gp || !is_device_ptr(mloc.gp))
+        return fail(FEMASM_ERR_ARG, "femasm_assemble_interface needs the material array in device memory");
+      if (mloc.stride < need) return fail(FEMASM_ERR_ARG, "material stride %d < %d", mloc.stride, need);
+      if (mloc.e_ks > p->s.els) return fail(FEMASM_ERR_ARG, "material starts above the first assembled element layer");
+    } else if (mloc.layout != FEMASM_MAT_UNIFORM) {
+      return fail(FEMASM_ERR_ARG, "unknown material layout %d", mloc.layout);
+    }
+    p->s.mat_e_ks = (mloc.layout == FEMASM_MAT_AOS) ? mloc.e_ks : p->s.els;
+  } else {
+    mloc.layout = FEMASM_MAT_UNIFORM;
+  }
+  const Slab &s = p->s;
+  if (s.ks == 0) { p->iface_done = true; return FEMASM_OK; }  // lowest slab: nothing is owed
+  if (!p->send) return fail(FEMASM_ERR_ARG, "no send buffer");
+  p->time_main = false;
+  int rc = 0;
+  unsigned long long flags[2] = {0, 0};
+  for (int attempt = 0; attempt < 2; attempt++) {
+    p->used_fast = false;
+    HIPCHK(hipMemsetAsync(p->bad, 0, 2 * sizeof(unsigned long long), p->stream));
+    switch (p->kind) {
+      case KIND_POISSON: rc = launch_K<KIND_POISSON>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1); break;
+      case KIND_PLANE:   rc = launch_K<KIND_PLANE>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1); break;
+      case KIND_ELASTIC: rc = launch_K<KIND_ELASTIC>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1); break;
+    }
+    if (rc) return rc;
+    // one layer only: checking the fast kernel's premise here costs one short wait, and the caller is about to
+    // hand the buffer to the network, so it has to be final
+    HIPCHK(hipMemcpyAsync(flags, p->bad, sizeof flags, hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    if (!(p->used_fast && flags[1])) break;
+    p->fast_level = 0;
+  }
+  if (flags[0]) return fail(FEMASM_ERR_GEOMETRY, "%llu Gauss points with non-positive or NaN det(J)", flags[0]);
+  // element vectors of the one element layer that touches node layer ks-1 from above (it is the first layer
+  // of the plan's element-vector array, where the full call will write the same numbers again)
+  Slab sl = s;
+  sl.ele = sl.els + 1;
+  const int64_t eplane = (s.nsd == 3) ? (s.dim[0] - 1) * (s.dim[1] - 1) : (s.dim[0] - 1);
+  double *sb = p->send + p->send_nnz;
+  switch (p->kind) {
+    case KIND_POISSON: rc = launch_rhs<KIND_POISSON>(p, &mloc, bc, sb, s.ks - 1, s.ks, 1, true, &sl, eplane); break;
+    case KIND_PLANE:   rc = launch_rhs<KIND_PLANE>(p, &mloc, bc, sb, s.ks - 1, s.ks, 1, true, &sl, eplane); break;
+    case KIND_ELASTIC: rc = launch_rhs<KIND_ELASTIC>(p, &mloc, bc, sb, s.ks - 1, s.ks, 1, true, &sl, eplane); break;
+  }
+  if (rc) return rc;
+  p->iface_done = true;
   return FEMASM_OK;
 }
 

@@ -30,7 +30,7 @@ EXPORTS = [
     "femasm_plan_create", "femasm_plan_destroy", "femasm_plan_set_stream", "femasm_pattern",
     "femasm_pattern_copy", "femasm_scatter_map", "femasm_assemble_system", "femasm_interface_buffers",
     "femasm_interface_set_buffers", "femasm_interface_apply", "femasm_compress_bc_rows", "femasm_plan_sync", "femasm_last_error",
-    "femasm_version", "femasm_plan_set_fast_path", "femasm_plan_get_fast_path",
+    "femasm_version", "femasm_plan_set_fast_path", "femasm_plan_get_fast_path", "femasm_assemble_interface",
 ]
 
 
@@ -185,6 +185,15 @@ class Plan:
         _check(load().femasm_assemble_system(self._h, C.byref(mat), C.byref(bcs), _ptr(values), _ptr(b),
                                              C.byref(st) if want_stats else None))
         return st if want_stats else None
+
+    def assemble_interface(self, material=None, bc=BC_NONE, E=0.0, nu=0.0, stride=0, e_ks=None):
+        """First half of a split call: fill the send buffer only, asynchronously (see include/femasm.h)."""
+        if material is None:
+            mat = Material(MAT_UNIFORM, 0, 0, None, E, nu)
+        else:
+            mat = Material(MAT_AOS, stride, self.els if e_ks is None else e_ks, _ptr(material), E, nu)
+        bcs = BC(bc, 0)
+        _check(load().femasm_assemble_interface(self._h, C.byref(mat), C.byref(bcs)))
 
     def interface_buffers(self):
         sb, rb = C.c_void_p(), C.c_void_p()

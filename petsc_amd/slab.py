@@ -72,3 +72,21 @@ def exchange_interface(send, recv, rank, world):
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+
+
+def exchange_interface_start(send, recv, rank, world):
+    """Non-blocking form: enqueue the send to r-1 / receive from r+1 behind the work already queued on the current
+    stream and return the requests (RCCL moves the data on its own stream while later kernels run)."""
+    if world == 1:
+        return []
+    ops = []
+    if rank > 0 and send is not None and send.numel() > 0:
+        ops.append(dist.P2POp(dist.isend, send, rank - 1))
+    if rank < world - 1 and recv is not None and recv.numel() > 0:
+        ops.append(dist.P2POp(dist.irecv, recv, rank + 1))
+    return dist.batch_isend_irecv(ops) if ops else []
+
+
+def exchange_interface_finish(reqs):
+    for w in reqs or []:
+        w.wait()

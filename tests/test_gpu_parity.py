@@ -195,9 +195,11 @@ def test_compressed_bc_rows_match_petsc_matzerorows_default(env, kind, dims):
 
 @pytest.mark.parametrize("kind,dims,nslab", [("p3", (5, 4, 9), 3), ("e2", (9, 11), 2), ("s3", (4, 5, 8), 2),
                                              ("s3", (3, 3, 7), 4)])
-def test_slabs_plus_interface_exchange_equal_the_global_system(env, kind, dims, nslab):
+@pytest.mark.parametrize("split", [False, True])
+def test_slabs_plus_interface_exchange_equal_the_global_system(env, kind, dims, nslab, split):
     """Multi-GPU path on one device: one plan per slab, the send buffer of slab r+1 handed to slab r
-    (what RCCL does in bench.py), then femasm_interface_apply."""
+    (what RCCL does in bench.py), then femasm_interface_apply.  split: the send buffer is produced by
+    femasm_assemble_interface ahead of the full call (the overlap path of bench.py --gpus N)."""
     torch, F, dev, slab = env["torch"], env["F"], env["dev"], env["slab"]
     case = make_case(env, kind, dims, vary_material=(kind != "p3"))
     M, N, P = case["dims"]
@@ -222,7 +224,12 @@ def test_slabs_plus_interface_exchange_equal_the_global_system(env, kind, dims, 
         send = torch.full((max(sc, 1),), float("nan"), dtype=torch.float64, device=dev)
         recv = torch.full((max(rc, 1),), float("nan"), dtype=torch.float64, device=dev)
         plan.interface_set_buffers(send if sc else None, recv if rc else None)
+        if split:
+            plan.assemble_interface(material=mat, stride=case["stride"], bc=case["bc"], e_ks=els)
+            sent = send.clone()  # what the network would have taken at this point
         plan.assemble_system(vals, b, material=mat, stride=case["stride"], bc=case["bc"], e_ks=els)
+        if split and sc:
+            assert torch.equal(sent[:sc], send[:sc])  # the full call left the buffer alone
         plans.append(plan); outs.append((vals, b)); bufs.append((send, recv, sc, rc))
     for r in range(nslab - 1):
         assert bufs[r][3] == bufs[r + 1][2]
