@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void k_assemble_rows(const Slab s, const KA
 // ---------------------------------------------------------------------------
 #define PH_BUF a.bad
 #if FEMASM_EXP == 3  // phase clocks (profiling build only): PH_ACC(p, id) adds the time since the last mark to phase p
-#define PH_DECL unsigned long long ph_[4] = {0, 0, 0, 0}, ph_n = 0, ph_t = 0
+#define PH_DECL unsigned long long ph_[4] = {0, 0, 0, 0}, ph_n = 0, ph_t = __builtin_readcyclecounter()
 #define PH_T(id) ph_t = __builtin_readcyclecounter(), ph_n++
 #define PH_ACC(p, id)                                            \
   do {                                                           \
@@ -631,6 +631,31 @@ __global__ __launch_bounds__(256) void k_rhs_elem(const Slab s, const RArgs a) {
     }
     if constexpr (KIND == KIND_POISSON) {
       constexpr double PI = 3.14159265358979323846264338327950288;
+      // axis-aligned box (every element of a DMDASetUniformCoordinates mesh): the Gauss points are a tensor grid,
+      // so 6 sines instead of 24 and one det(J); tested exactly per element, other elements take the general loop
+      bool box = true;
+#pragma unroll
+      for (int n = 0; n < 8; n++) {
+        box = box && xc[3 * n] == xc[3 * (HDI[n] ? 3 : 0)] && xc[3 * n + 1] == xc[3 * (HDJ[n] ? 1 : 0) + 1] &&
+              xc[3 * n + 2] == xc[3 * (HDK[n] ? 4 : 0) + 2];
+      }
+      if (box) {
+        const double h[3] = {xc[9] - xc[0], xc[4] - xc[1], xc[14] - xc[2]};
+        const double fac = 1.0 * ((0.5 * h[0]) * (0.5 * h[1]) * (0.5 * h[2]));
+        double sn[3][2];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          const double lo = xc[d], hi = xc[(d == 0 ? 9 : (d == 1 ? 3 : 12)) + d];
+          const double a0 = 0.5 * (1.0 + GAUSS_G), a1 = 0.5 * (1.0 - GAUSS_G);
+          sn[d][0] = sinpi(a0 * lo + a1 * hi);  // Gauss abscissa -g
+          sn[d][1] = sinpi(a1 * lo + a0 * hi);  // Gauss abscissa +g
+        }
+        for (int p = 0; p < 8; p++) {
+          const double fv = 3.0 * PI * PI * sn[0][HDI[p]] * sn[1][HDJ[p]] * sn[2][HDK[p]];
+#pragma unroll
+          for (int i = 0; i < 8; i++) F[i] += fac * fv * c_tab3.N[p][i];
+        }
+      } else
       for (int p = 0; p < 8; p++) {  // P3:549-566
         const double fac = 1.0 * det3_only(c_tab3.G[p], xc);
         double pos[3] = {0.0, 0.0, 0.0};
@@ -638,7 +663,8 @@ __global__ __launch_bounds__(256) void k_rhs_elem(const Slab s, const RArgs a) {
         for (int n = 0; n < 8; n++)
 #pragma unroll
           for (int d = 0; d < 3; d++) pos[d] += c_tab3.N[p][n] * xc[3 * n + d];
-        const double fv = 3.0 * PI * PI * sin(PI * pos[0]) * sin(PI * pos[1]) * sin(PI * pos[2]);
+        // sinpi: the reference's sin(pi*x) without the large-argument reduction (differs by ~1 ulp of the argument)
+        const double fv = 3.0 * PI * PI * sinpi(pos[0]) * sinpi(pos[1]) * sinpi(pos[2]);
 #pragma unroll
         for (int i = 0; i < 8; i++) F[i] += fac * fv * c_tab3.N[p][i];
       }
@@ -724,6 +750,7 @@ __global__ __launch_bounds__(256) void k_rhs_elem_elastic_coop(const Slab s, con
   if (tid < 192) (&sh_G[0][0][0])[tid] = (&c_tab3.G[0][0][0])[tid];
   __syncthreads();
 
+  PH_DECL;
   // two register sets, one per parity of the pair index: what a step commits was requested two steps earlier
   double2 pins[2][5];
   double pxcs[2] = {0.0, 0.0};
@@ -778,7 +805,6 @@ __global__ __launch_bounds__(256) void k_rhs_elem_elastic_coop(const Slab s, con
     request(16 * g + el, pins[0], pxcs[0]);
     request(16 * g + 2 + el, pins[1], pxcs[1]);
   }
-  PH_DECL;
   for (; g < ngroups; g += gstride) {
 #pragma unroll 1
     for (int it2 = 0; it2 < 4; it2++) {
@@ -907,12 +933,16 @@ __global__ __launch_bounds__(256) void k_rhs_gather(const Slab s, const RArgs a)
   for (int c = 0; c < DOF; c++) b[c] = 0.0;
 
   if constexpr (NSD == 3) {
+    const int64_t e111 = i + mx * (j + my * (k - s.els));  // element (i,j,k); the others by constant offsets
+#pragma unroll
     for (int oz = -1; oz <= 0; oz++)
+#pragma unroll
       for (int oy = -1; oy <= 0; oy++)
+#pragma unroll
         for (int ox = -1; ox <= 0; ox++) {
           const int64_t ex = i + ox, ey = j + oy, ez = k + oz;
           if (ex < 0 || ex >= mx || ey < 0 || ey >= my || ez < s.els || ez >= s.ele) continue;
-          const double *F = a.elemF + (ex + mx * (ey + my * (ez - s.els)));
+          const double *F = a.elemF + (e111 + ox + mx * (oy + my * oz));
           const int al = hex_idx(-ox, -oy, -oz);
 #pragma unroll
           for (int c = 0; c < DOF; c++) b[c] = b[c] + F[(al * DOF + c) * a.nelp];
