@@ -101,10 +101,11 @@ int femasm_plan_destroy(femasm_plan *plan);
 /* Launch everything on `stream` (a hipStream_t) instead of the plan's own stream. */
 int femasm_plan_set_stream(femasm_plan *plan, void *stream);
 
-/* No counterpart in the reference (an optimisation switch of this engine).  The 3-D kinds
- * have a specialised stiffness kernel besides the general one:
- *   level 2  elastic: axis-aligned box elements (what DMDASetUniformCoordinates P3:663 /
- *            S3:1198 produces) with one (E,nu) per element; Poisson: as level 1
+/* No counterpart in the reference (an optimisation switch of this engine).  Every kind
+ * has a specialised stiffness kernel besides the general one:
+ *   level 2  elastic (2-D and 3-D): axis-aligned box / rectangle elements (what
+ *            DMDASetUniformCoordinates P3:663 / E2:577 / S3:1198 produces) with one (E,nu)
+ *            per element; Poisson: as level 1
  *   level 1  Poisson: affine elements (parallelepipeds); elastic: as level 0
  *   level 0  general isoparametric elements, (E,nu) per Gauss point
  * The specialised kernel tests its premise on every element it touches, exactly (bitwise-equal

@@ -159,11 +159,34 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
   const int64_t M = p->s.dim[0], N = p->s.dim[1], P = p->s.dim[2];
   if constexpr (T::NSD == 2) {
     const bool timed = p->time_main && !iface;
+    const bool aos2 = mat && mat->layout == FEMASM_MAT_AOS;
+    const int64_t y0 = s0 > 1 ? s0 : 1, y1 = s1 < N - 1 ? s1 : N - 1;
+    if (p->fast_level == 2 && !iface && M > 2 && y1 > y0) {
+      // interior nodes: 2-D row sweep (rectangles, one (E,nu) per element; verified in the kernel)
+      const Box b{1, M - 1, 0, 1, y0, y1};
+      const KArgs a = make_kargs<KIND>(p, mat, bc, out, b, s0, iface);
+      dim3 grid((unsigned)((b.x1 - b.x0 + RS2_TX - 1) / RS2_TX), (unsigned)((y1 - y0 + RS2_YC - 1) / RS2_YC), 1);
+      if (timed) HIPCHK(hipEventRecord(p->ev[4], p->stream));
+      hipLaunchKernelGGL(k_assemble_rowsweep2d, grid, dim3(192), 0, p->stream, p->s, a);
+      HIPCHK(hipGetLastError());
+      p->used_fast = true;
+      if (timed) {
+        HIPCHK(hipEventRecord(p->ev[5], p->stream));
+        const double nint = (double)(M - 2) * (double)(y1 - y0);
+        p->bytes_main = 8.0 * nint * 36.0 + 8.0 * 2.0 * (double)M * (y1 - y0 + 2) +
+                        (aos2 ? 16.0 * 4.0 * (double)(M - 1) * (y1 - y0 + 1) : 0.0);
+      }
+      // the four edges of the node grid (Dirichlet columns i = 0, M-1 and the rows j = 0, N-1): brick kernel
+      int rc2 = launch_brick<KIND>(p, mat, bc, out, Box{0, 1, 0, 1, y0, y1}, s0, iface);
+      if (!rc2) rc2 = launch_brick<KIND>(p, mat, bc, out, Box{M - 1, M, 0, 1, y0, y1}, s0, iface);
+      if (!rc2 && s0 == 0) rc2 = launch_brick<KIND>(p, mat, bc, out, Box{0, M, 0, 1, 0, 1}, s0, iface);
+      if (!rc2 && s1 == N && N - 1 >= s0 && N > 1) rc2 = launch_brick<KIND>(p, mat, bc, out, Box{0, M, 0, 1, N - 1, N}, s0, iface);
+      return rc2;
+    }
     if (timed) HIPCHK(hipEventRecord(p->ev[4], p->stream));
     const int rc2 = launch_brick<KIND>(p, mat, bc, out, Box{0, M, 0, 1, s0, s1}, s0, iface);
     if (timed) {
       HIPCHK(hipEventRecord(p->ev[5], p->stream));
-      const bool aos2 = mat && mat->layout == FEMASM_MAT_AOS;
       p->bytes_main = 8.0 * p->nnz + 8.0 * T::NSD * p->nnodes + (aos2 ? 16.0 * T::NGP * p->nel : 0.0);
     }
     return rc2;

@@ -32,6 +32,20 @@ __global__ __launch_bounds__(256) void p1(double *out, int64_t ntile, int iters)
     }
   }
 }
+// P1nt: as P1 (8-byte stores) with non-temporal stores
+__global__ __launch_bounds__(256) void p1nt(double *out, int64_t ntile, int iters) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (w == 3) return;
+  for (int it = 0; it < iters; it++) {
+    const int64_t tile = blockIdx.x + (int64_t)it * gridDim.x;
+    if (tile >= ntile) break;
+    double *p = out + (tile * 64 + lane) * NB + w * NR;
+    const double v = lane + it;
+#pragma unroll
+    for (int k = 0; k < 81; k++) __builtin_nontemporal_store(v, p + k);
+  }
+}
 // P3: transposed: wave w<3 writes row c=w of 64 nodes as 81 instructions of 64 consecutive values of [node][81]
 __global__ __launch_bounds__(256) void p3(double *out, int64_t ntile, int iters) {
   extern __shared__ double lds[];
@@ -156,6 +170,8 @@ int main() {
     timeit("P0 linear fill 16B/lane", bytes, [&] { p0<<<256 * 8, 256>>>(out, (int64_t)(bytes / 16)); });
     timeit("P1 row per lane, 16B stores (stride 1944B)", bytes, [&] { p1<1><<<grid, 256, lds>>>(out, ntile, iters); });
     timeit("P1 row per lane, 8B stores", bytes, [&] { p1<0><<<grid, 256, lds>>>(out, ntile, iters); });
+    hipFuncSetAttribute((const void *)p1nt, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    timeit("P1 row per lane, 8B non-temporal stores", bytes, [&] { p1nt<<<grid, 256, lds>>>(out, ntile, iters); });
     timeit("P3 row transposed, 648B runs, 8B/lane", bytes, [&] { p3<<<grid, 256, lds>>>(out, ntile, iters); });
     timeit("P4 whole block contiguous 16B/lane", bytes, [&] { p4<<<grid, 256, lds>>>(out, ntile, iters); });
     timeit("P5 thirds transposed, 216B runs (current)", bytes, [&] { p5<<<grid, 256, lds>>>(out, ntile, iters); });

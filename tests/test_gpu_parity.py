@@ -332,9 +332,9 @@ def test_sheared_mesh_elastic_falls_back_poisson_stays_fast(env):
     plan.close()
 
 
-@pytest.mark.parametrize("kind", ["p3", "s3"])
+@pytest.mark.parametrize("kind", ["p3", "s3", "e2"])
 def test_general_geometry_drops_to_the_general_kernel(env, kind):
-    case = make_case(env, kind, (8, 7, 9), perturb=True)
+    case = make_case(env, kind, (70, 40) if kind == "e2" else (8, 7, 9), perturb=True)
     plan, vals, b = gpu_assemble(env, case)
     assert plan.fast_path() == 0
     assert rel(vals, case["K"]) <= TOL
@@ -363,11 +363,11 @@ def test_material_varying_inside_an_element_falls_back(env):
     plan.close()
 
 
-@pytest.mark.parametrize("kind", ["p3", "s3"])
+@pytest.mark.parametrize("kind", ["p3", "s3", "e2"])
 @pytest.mark.parametrize("level", [0, 1, 2])
 def test_all_kernel_levels_agree_with_the_oracle_on_a_uniform_mesh(env, kind, level):
     torch, F, dev = env["torch"], env["F"], env["dev"]
-    case = make_case(env, kind, (20, 9, 19), perturb=False)
+    case = make_case(env, kind, (150, 71) if kind == "e2" else (20, 9, 19), perturb=False)
     M, N, P = case["dims"]
     plan = F.Plan(case["problem"], M, N, P, coords=torch.from_numpy(case["coords"]).to(dev))
     plan.set_fast_path(level)
@@ -376,4 +376,20 @@ def test_all_kernel_levels_agree_with_the_oracle_on_a_uniform_mesh(env, kind, le
     plan.assemble_system(vals, None, material=mat, stride=case["stride"], bc=case["bc"])
     assert plan.fast_path() == level
     assert rel(vals.cpu().numpy(), case["K"]) <= TOL
+    plan.close()
+
+
+def test_e2_material_varying_inside_an_element_falls_back(env):
+    case = make_case(env, "e2", (90, 37), perturb=False, vary_material=True)
+    plan, vals, b = gpu_assemble(env, case)
+    assert plan.fast_path() == 0
+    assert rel(vals, case["K"]) <= TOL and rel(b, case["b"]) <= TOL
+    plan.close()
+
+
+def test_e2_rectangles_keep_the_row_sweep(env):
+    case = make_case(env, "e2", (131, 67), perturb=False)  # two x tiles, ragged; three y chunks
+    plan, vals, b = gpu_assemble(env, case)
+    assert plan.fast_path() == 2
+    assert rel(vals, case["K"]) <= TOL and rel(b, case["b"]) <= TOL
     plan.close()
