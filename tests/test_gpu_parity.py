@@ -393,3 +393,21 @@ def test_e2_rectangles_keep_the_row_sweep(env):
     assert plan.fast_path() == 2
     assert rel(vals, case["K"]) <= TOL and rel(b, case["b"]) <= TOL
     plan.close()
+
+
+@pytest.mark.parametrize("kind,dims", [("p3", (9, 8, 10)), ("e2", (70, 33)), ("s3", (8, 7, 9))])
+@pytest.mark.parametrize("perturb", [False, True])
+def test_solution_of_the_assembled_system_matches_the_oracle_system(env, kind, dims, perturb):
+    """north_star: the KSP solution matches within 1e-12 relative.  KSP itself is out of scope; here both systems
+    (GPU-assembled and oracle-assembled) are solved by the same sparse direct solver."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    case = make_case(env, kind, dims, perturb=perturb)
+    plan, vals, b = gpu_assemble(env, case)
+    n = len(case["rp"]) - 1
+    Kg = sp.csr_matrix((vals, case["ci"], case["rp"]), shape=(n, n)).tocsc()
+    Ko = sp.csr_matrix((case["K"], case["ci"], case["rp"]), shape=(n, n)).tocsc()
+    ug, uo = spla.spsolve(Kg, b), spla.spsolve(Ko, case["b"])
+    assert np.isfinite(uo).all() and np.linalg.norm(uo) > 0
+    assert rel(ug, uo) <= 1e-12  # the north_star's tolerance
+    plan.close()
