@@ -163,6 +163,13 @@ int femasm_interface_apply(femasm_plan *plan, const femasm_bc *bc, double *csr_v
 int femasm_compress_bc_rows(femasm_plan *plan, const femasm_bc *bc, const double *csr_values,
                             int64_t *rowptr_out, int32_t *colidx_out, double *values_out, int64_t *nnz_out);
 
+/* SURVEY 8(f) row N3, the step after the solve: the element integrals of DMDAIntegrateErrors3D (P3:416-532,
+ * S3:1041-1151) over this slab's elements against the drivers' manufactured solutions.  u: the solution on the
+ * node layers [cks,cke) of the plan's coordinate array (the ghosted local vector of DMGlobalToLocal, P3:437),
+ * HOST or DEVICE.  sums[0] = sum of the L2 integrals, sums[1] = of the H1 integrals; the caller adds the ranks'
+ * sums (MPI_Allreduce, P3:510-513) and takes the square roots; h = 1/(M-1).  3-D kinds only. */
+int femasm_error_integrals(femasm_plan *plan, const double *u, double sums[2]);
+
 /* Block until everything queued on the plan's stream has finished. */
 int femasm_plan_sync(femasm_plan *plan);
 

@@ -731,6 +731,40 @@ int femasm_assemble_interface(femasm_plan *p, const femasm_material *mat, const 
   return FEMASM_OK;
 }
 
+int femasm_error_integrals(femasm_plan *p, const double *u, double sums[2]) {
+  if (!p || !u || !sums) return fail(FEMASM_ERR_ARG, "null argument");
+  if (p->kind == KIND_PLANE) return fail(FEMASM_ERR_ARG, "the reference has no error norms for the 2-D driver");
+  HIPCHK(hipSetDevice(p->device));
+  sums[0] = sums[1] = 0.0;
+  if (p->nel <= 0) return FEMASM_OK;
+  const Slab &s = p->s;
+  const int64_t nghost = (int64_t)s.dim[0] * s.dim[1] * (p->cke - s.cks) * s.dof;  // u has the layers of coords
+  const double *d_u = u;
+  double *stage = nullptr;
+  if (!is_device_ptr(u)) {
+    HIPCHK(hipMalloc(&stage, nghost * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(stage, u, nghost * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    d_u = stage;
+  }
+  const int64_t nb = (p->nel + 255) / 256;
+  double *partial = nullptr;
+  HIPCHK(hipMalloc(&partial, (2 * nb + 2) * sizeof(double)));
+  if (p->kind == KIND_POISSON)
+    hipLaunchKernelGGL(k_error_integrals<KIND_POISSON>, dim3((unsigned)nb), dim3(256), 0, p->stream, s, p->coords, d_u,
+                       p->nel, partial);
+  else
+    hipLaunchKernelGGL(k_error_integrals<KIND_ELASTIC>, dim3((unsigned)nb), dim3(256), 0, p->stream, s, p->coords, d_u,
+                       p->nel, partial);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, p->stream, partial, nb, partial + 2 * nb);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(sums, partial + 2 * nb, 2 * sizeof(double), hipMemcpyDeviceToHost, p->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+  (void)hipFree(partial);
+  if (stage) (void)hipFree(stage);
+  if (e != hipSuccess) return fail(FEMASM_ERR_HIP, "femasm_error_integrals: %s", hipGetErrorString(e));
+  return FEMASM_OK;
+}
+
 int femasm_interface_buffers(femasm_plan *p, double **send_buf, int64_t *send_count, double **recv_buf,
                              int64_t *recv_count) {
   if (!p) return fail(FEMASM_ERR_ARG, "null plan");

@@ -1009,6 +1009,95 @@ __global__ __launch_bounds__(256) void k_iface_apply(const Slab s, int bc, doubl
 }
 
 // ---------------------------------------------------------------------------
+// N3: error integrals against the manufactured solutions (DMDAIntegrateErrors3D, P3:416-532, S3:1041-1151):
+// per element  sum_p w detJ sum_i N_i e_i^2  and  sum_p w detJ sum_i |grad N_i|^2 e_i^2  with e = nodal error
+// (the reference's nodal form).  One thread per element, fixed-order tree per workgroup -> partial[2*block],
+// a second one-workgroup launch sums the partials: deterministic, no atomics.
+// ---------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(256) void k_error_integrals(const Slab s, const double *coords, const double *u,
+                                                         int64_t nel, double *partial) {
+  constexpr int DOF = Traits<KIND>::DOF;
+  constexpr double PI = 3.14159265358979323846264338327950288;
+  __shared__ double red[2][256];
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t M = s.dim[0], N = s.dim[1];
+  const int64_t mx = M - 1, my = N - 1;
+  double eL2 = 0.0, eH1 = 0.0;
+  if (e < nel) {
+    const int64_t ex = e % mx, ey = (e / mx) % my, ez = s.els + e / (mx * my);
+    double xc[24], err2[8];
+#pragma unroll
+    for (int n = 0; n < 8; n++) {
+      const int64_t node = (ex + HDI[n]) + M * ((ey + HDJ[n]) + N * (ez + HDK[n] - s.cks));
+#pragma unroll
+      for (int d = 0; d < 3; d++) xc[3 * n + d] = coords[3 * node + d];
+      const double ua = sin(PI * xc[3 * n]) * sin(PI * xc[3 * n + 1]) * sin(PI * xc[3 * n + 2]);
+      if constexpr (DOF == 1) {
+        const double d0 = u[node] - ua;
+        err2[n] = d0 * d0;
+      } else {  // exact displacement (0, 0, sin sin sin), S3:964-968
+        const double d0 = u[3 * node] - 0.0, d1 = u[3 * node + 1] - 0.0, d2 = u[3 * node + 2] - ua;
+        err2[n] = d0 * d0 + d1 * d1 + d2 * d2;
+      }
+    }
+    for (int p = 0; p < 8; p++) {
+      const double(*G)[8] = c_tab3.G[p];
+      const Jac3 jj = jac3(G, xc);
+      const double fac = 1.0 * jj.det;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        double g2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const double gk = G[0][i] * jj.iJ[k][0] + G[1][i] * jj.iJ[k][1] + G[2][i] * jj.iJ[k][2];
+          g2 += gk * gk;
+        }
+        eL2 += fac * c_tab3.N[p][i] * err2[i];
+        eH1 += fac * g2 * err2[i];
+      }
+    }
+  }
+  red[0][threadIdx.x] = eL2;
+  red[1][threadIdx.x] = eH1;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + st];
+      red[1][threadIdx.x] += red[1][threadIdx.x + st];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = red[0][0];
+    partial[2 * blockIdx.x + 1] = red[1][0];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_sum_partials(const double *partial, int64_t n, double *out) {
+  __shared__ double red[2][256];
+  double a0 = 0.0, a1 = 0.0;
+  for (int64_t q = threadIdx.x; q < n; q += 256) {
+    a0 += partial[2 * q];
+    a1 += partial[2 * q + 1];
+  }
+  red[0][threadIdx.x] = a0;
+  red[1][threadIdx.x] = a1;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + st];
+      red[1][threadIdx.x] += red[1][threadIdx.x + st];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = red[0][0];
+    out[1] = red[1][0];
+  }
+}
+
+// ---------------------------------------------------------------------------
 // pattern (A12) and explicit scatter map (A13)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pattern(const Slab s, int64_t nrows, int64_t *rowptr, int32_t *colidx) {

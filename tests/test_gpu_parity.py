@@ -411,3 +411,38 @@ def test_solution_of_the_assembled_system_matches_the_oracle_system(env, kind, d
     assert np.isfinite(uo).all() and np.linalg.norm(uo) > 0
     assert rel(ug, uo) <= 1e-12  # the north_star's tolerance
     plan.close()
+
+
+# ---- N3: error integrals (DMDAIntegrateErrors3D) ----
+@pytest.mark.parametrize("kind,dims", [("p3", (9, 7, 8)), ("s3", (6, 8, 7))])
+@pytest.mark.parametrize("host", [False, True])
+def test_error_integrals_match_the_oracle(env, kind, dims, host):
+    torch, F, dev, O = env["torch"], env["F"], env["dev"], env["O"]
+    M, N, P = dims
+    dof = 1 if kind == "p3" else 3
+    coords = O.perturb_coords(O.uniform_coords(3, M, N, P), 3, M, N, P)
+    rng = np.random.default_rng(11)
+    u = rng.uniform(-1, 1, size=M * N * P * dof)
+    h, l2, h1 = O.errors(kind, M, N, P, coords, u)
+    plan = F.Plan(F.POISSON3D_Q1 if kind == "p3" else F.ELASTIC3D_Q1, M, N, P, coords=torch.from_numpy(coords).to(dev))
+    s0, s1 = plan.error_integrals(u if host else torch.from_numpy(u).to(dev))
+    assert abs(np.sqrt(s0) - l2) <= 1e-12 * l2 and abs(np.sqrt(s1) - h1) <= 1e-12 * h1
+    assert h == 1.0 / (M - 1)
+    plan.close()
+
+
+def test_error_integrals_add_up_over_slabs(env):
+    torch, F, dev, O, slab = env["torch"], env["F"], env["dev"], env["O"], env["slab"]
+    M, N, P = 6, 5, 11
+    coords = O.perturb_coords(O.uniform_coords(3, M, N, P), 3, M, N, P)
+    u = np.random.default_rng(5).uniform(-1, 1, size=M * N * P * 3)
+    _, l2, h1 = O.errors("s3", M, N, P, coords, u)
+    tot = np.zeros(2)
+    for (ks, ke) in slab.slab_ranges(P, 3):
+        cks, cke = max(ks - 1, 0), min(ke + 1, P)
+        co = torch.from_numpy(coords.reshape(P, -1)[cks:cke].reshape(-1).copy()).to(dev)
+        ul = torch.from_numpy(u.reshape(P, -1)[cks:cke].reshape(-1).copy()).to(dev)
+        plan = F.Plan(F.ELASTIC3D_Q1, M, N, P, coords=co, ks=ks, ke=ke, cks=cks, cke=cke)
+        tot += plan.error_integrals(ul)  # the MPI_Allreduce of S3:1137-1138
+        plan.close()
+    assert abs(np.sqrt(tot[0]) - l2) <= 1e-12 * l2 and abs(np.sqrt(tot[1]) - h1) <= 1e-12 * h1
