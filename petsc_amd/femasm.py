@@ -138,8 +138,8 @@ class Plan:
         self.nel = plane_e * max(self.ele - self.els, 0)
 
     def close(self):
-        if getattr(self, "_h", None):
-            load().femasm_plan_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:  # _lib is gone at interpreter shutdown
+            _lib.femasm_plan_destroy(self._h)
             self._h = None
 
     __del__ = close
