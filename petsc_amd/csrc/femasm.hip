@@ -216,7 +216,7 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
         constexpr int TX = RowSweep<KIND>::TX, TY = RowSweep<KIND>::TY;
         dim3 grid((unsigned)((b.x1 - b.x0 + TX - 1) / TX), (unsigned)((b.y1 - b.y0 + TY - 1) / TY),
                   (unsigned)((z1 - z0 + RS_ZC - 1) / RS_ZC));
-        hipLaunchKernelGGL(k_assemble_rowsweep<KIND>, grid, dim3(256), 0, p->stream, p->s, a);
+        hipLaunchKernelGGL(k_assemble_rowsweep<KIND>, grid, dim3(64 * (3 + RowSweep<KIND>::NRW)), 0, p->stream, p->s, a);
         p->used_fast = true;
       } else {
         dim3 grid((unsigned)((b.x1 - b.x0 + SW_TX - 1) / SW_TX), (unsigned)((b.y1 - b.y0 + SW_TY - 1) / SW_TY),

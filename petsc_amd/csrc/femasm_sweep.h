@@ -398,6 +398,7 @@ struct RowSweep {
   static constexpr int RUN = TX * NB;                       // doubles of a tile-row run
   static constexpr int CPASS = (NXL + 63) / 64;             // coordinate passes of the record wave
   static constexpr int EPASS = (NEL + 63) / 64;             // element passes of the record wave
+  static constexpr int NRW = 1;  // record waves; 2 for Poisson was measured slower (2.17 vs 1.62 ms): the polling hand-shake costs more than it saves
 };
 constexpr int RS_ZC = 16;  // node layers per workgroup
 
@@ -566,16 +567,17 @@ __device__ inline void rowsweep_row_wave(const Slab &s, const KArgs &a, const do
 }
 
 template <int KIND>
-__global__ __launch_bounds__(256, 2) void k_assemble_rowsweep(const Slab s, const KArgs a) {
+__global__ __launch_bounds__(64 * (3 + RowSweep<KIND>::NRW), 2) void k_assemble_rowsweep(const Slab s, const KArgs a) {
   using R_ = RowSweep<KIND>;
   constexpr int DOF = R_::DOF, NS = R_::NS, NPA = R_::NPA, SY = R_::SY, NXX = R_::NXX, NXL = R_::NXL;
-  constexpr int NEX = R_::NEX, NEL = R_::NEL, CPASS = R_::CPASS, EPASS = R_::EPASS;
+  constexpr int NEX = R_::NEX, NEL = R_::NEL, CPASS = R_::CPASS, EPASS = R_::EPASS, NRW = R_::NRW;
   constexpr bool HASMAT = (KIND != KIND_POISSON);
 
   __shared__ double2 sh_rec[3 * NPA * NS];  // ring: element layer L0+q in slot q % 3
   __shared__ double sh_stage[R_::RUN];      // one tile-row run in HBM order
   __shared__ double sh_x[3][NXL * 3];       // ring of node layers (record wave only): layer L0+q in slot q % 3
   __shared__ unsigned sh_cnt;               // arrival counter of row_waves_sync
+  __shared__ unsigned sh_cnt2;              // the same among the record waves
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -586,9 +588,10 @@ __global__ __launch_bounds__(256, 2) void k_assemble_rowsweep(const Slab s, cons
   const int nz = (int)(zc1 - zc0);
   const int64_t L0 = zc0 - 1;
 
-  if (tid == 0) sh_cnt = 0;
+  if (tid == 0) sh_cnt = sh_cnt2 = 0;
   if (wu < 3) {
-    __syncthreads();  // matches the record wave's prologue
+    __syncthreads();  // counters initialised
+    __syncthreads();  // matches the record waves' prologue
     if constexpr (DOF == 1) {
       rowsweep_row_wave<KIND, 0>(s, a, sh_rec, sh_stage, &sh_cnt, wu, lane, i0, j0, zc0, nz);
     } else {
@@ -602,10 +605,17 @@ __global__ __launch_bounds__(256, 2) void k_assemble_rowsweep(const Slab s, cons
   // ------------------------------- record wave -------------------------------
   __builtin_amdgcn_s_setprio(3);  // its few memory instructions should not queue behind the row waves' stores
   const bool aos = HASMAT && a.mat_layout == 0;
+  const int rw = wu - 3;  // record wave index: it takes the passes ps = rw (mod NRW)
+  unsigned epoch2 = 0;
+  auto record_waves_sync = [&](int ln) {
+    if constexpr (NRW > 1) row_waves_sync<NRW>(&sh_cnt2, epoch2, ln, a.bad);
+  };
+  __syncthreads();  // counters initialised
   auto load_layer = [&](int64_t gk, double (*cr)[3], int ln) {  // node layer gk of the halo'd tile -> registers
     gk = gk < s.cks ? s.cks : (gk > a.cke - 1 ? a.cke - 1 : gk);
 #pragma unroll
     for (int ps = 0; ps < CPASS; ps++) {
+      if (ps % NRW != rw) continue;
       const int q = ln + 64 * ps;
       if (q < NXL) {
         const int cy = q / NXX, cx = q - NXX * cy;
@@ -624,6 +634,7 @@ __global__ __launch_bounds__(256, 2) void k_assemble_rowsweep(const Slab s, cons
   auto commit_layer = [&](int slot, const double (*cr)[3], int ln) {
 #pragma unroll
     for (int ps = 0; ps < CPASS; ps++) {
+      if (ps % NRW != rw) continue;
       const int q = ln + 64 * ps;
       if (q < NXL) {
 #pragma unroll
@@ -791,6 +802,7 @@ __global__ __launch_bounds__(256, 2) void k_assemble_rowsweep(const Slab s, cons
     load_layer(L0 + q, cr[0], lane);
     commit_layer(q, cr[0], lane);
   }
+  record_waves_sync(lane);  // every record wave has staged its share of the three node layers
 #pragma unroll 1
   for (int q = 0; q < 2; q++) {
     load_mat(L0 + q, mraw[0], lane);
@@ -798,7 +810,8 @@ __global__ __launch_bounds__(256, 2) void k_assemble_rowsweep(const Slab s, cons
     lds_fence();
 #pragma unroll
     for (int ps = 0; ps < EPASS; ps++)
-      build_records(L0 + q, sh_x[q], sh_x[q + 1], sh_rec + q * (NPA * NS), lane, ps, mE[ps], mNu[ps]);
+      if (ps % NRW == rw)
+        build_records(L0 + q, sh_x[q], sh_x[q + 1], sh_rec + q * (NPA * NS), lane, ps, mE[ps], mNu[ps]);
   }
   load_layer(L0 + 3, cr[0], lane);
   load_mat(L0 + 2, mraw[0], lane);
@@ -823,10 +836,12 @@ __global__ __launch_bounds__(256, 2) void k_assemble_rowsweep(const Slab s, cons
         load_mat(L0 + st + 4, mrawp, ln);
       }
       lds_fence();
+      record_waves_sync(ln);  // the new node layer is complete
       PH_ACC(1, 2);
 #pragma unroll
       for (int ps = 0; ps < EPASS; ps++)
-        build_records(L0 + st + 2, sh_x[q3b], sh_x[q3], sh_rec + q3b * (NPA * NS), ln, ps, mE[ps], mNu[ps]);
+        if (ps % NRW == rw)
+          build_records(L0 + st + 2, sh_x[q3b], sh_x[q3], sh_rec + q3b * (NPA * NS), ln, ps, mE[ps], mNu[ps]);
       PH_ACC(2, 3);
     }
     q3 = q3a;
