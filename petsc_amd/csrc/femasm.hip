@@ -380,7 +380,7 @@ int femasm_plan_create(const femasm_mesh *mesh, const femasm_quad *quad, int dev
 
   PCHK(hipMalloc(&p->rowptr, (p->nrows + 1) * sizeof(int64_t)));
   PCHK(hipMalloc(&p->colidx, (size_t)(p->nnz > 0 ? p->nnz : 1) * sizeof(int32_t)));
-  PCHK(hipMalloc(&p->bad, 32 * sizeof(unsigned long long)));  // [0] bad detJ, [1] fast-path premise failures, rest: profiling builds
+  PCHK(hipMalloc(&p->bad, 32 * sizeof(unsigned long long)));  // [0] bad detJ, [1] fast-path premise failures, [2] hand-shake timeouts, rest: profiling builds
   PCHK(hipMemsetAsync(p->bad, 0, 32 * sizeof(unsigned long long), p->stream));
   PCHK(hipMalloc(&p->elemF, (size_t)(((p->nel > 0 ? p->nel : 1) + 15) & ~(int64_t)15) * nen * dof * sizeof(double)));
 
@@ -543,7 +543,7 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
   }
   ms_staging += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
-  HIPCHK(hipMemsetAsync(p->bad, 0, 2 * sizeof(unsigned long long), p->stream));
+  HIPCHK(hipMemsetAsync(p->bad, 0, 3 * sizeof(unsigned long long), p->stream));
 
   int rc = 0;
   // ---- K ----
@@ -596,7 +596,7 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
   t0 = std::chrono::steady_clock::now();
   if (vals_host) HIPCHK(hipMemcpyAsync(csr_values, d_vals, p->nnz * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   if (b_host) HIPCHK(hipMemcpyAsync(b, d_b, p->nrows * sizeof(double), hipMemcpyDeviceToHost, p->stream));
-  unsigned long long flags[2] = {0, 0};
+  unsigned long long flags[3] = {0, 0, 0};
   HIPCHK(hipMemcpyAsync(flags, p->bad, sizeof flags, hipMemcpyDeviceToHost, p->stream));
   HIPCHK(hipStreamSynchronize(p->stream));
   if (vals_host || b_host)
@@ -610,7 +610,7 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
     // the first attempt.
     p->fast_level = 0;
     p->used_fast = false;
-    HIPCHK(hipMemsetAsync(p->bad, 0, 2 * sizeof(unsigned long long), p->stream));
+    HIPCHK(hipMemsetAsync(p->bad, 0, 3 * sizeof(unsigned long long), p->stream));
     t0 = std::chrono::steady_clock::now();
     rc = run_K();
     if (rc) return rc;
@@ -624,6 +624,8 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
       ms_staging += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
   }
+  p->iface_done = false;
+  if (flags[2]) return fail(FEMASM_ERR_HIP, "internal: %llu wave hand-shakes of the row-sweep kernel timed out", flags[2]);
   const unsigned long long bad = flags[0];
 
   if (stats) {
@@ -697,10 +699,10 @@ int femasm_assemble_interface(femasm_plan *p, const femasm_material *mat, const 
   if (!p->send) return fail(FEMASM_ERR_ARG, "no send buffer");
   p->time_main = false;
   int rc = 0;
-  unsigned long long flags[2] = {0, 0};
+  unsigned long long flags[3] = {0, 0, 0};
   for (int attempt = 0; attempt < 2; attempt++) {
     p->used_fast = false;
-    HIPCHK(hipMemsetAsync(p->bad, 0, 2 * sizeof(unsigned long long), p->stream));
+    HIPCHK(hipMemsetAsync(p->bad, 0, 3 * sizeof(unsigned long long), p->stream));
     switch (p->kind) {
       case KIND_POISSON: rc = launch_K<KIND_POISSON>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1); break;
       case KIND_PLANE:   rc = launch_K<KIND_PLANE>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1); break;
@@ -714,6 +716,7 @@ int femasm_assemble_interface(femasm_plan *p, const femasm_material *mat, const 
     if (!(p->used_fast && flags[1])) break;
     p->fast_level = 0;
   }
+  if (flags[2]) return fail(FEMASM_ERR_HIP, "internal: %llu wave hand-shakes of the row-sweep kernel timed out", flags[2]);
   if (flags[0]) return fail(FEMASM_ERR_GEOMETRY, "%llu Gauss points with non-positive or NaN det(J)", flags[0]);
   // element vectors of the one element layer that touches node layer ks-1 from above (it is the first layer
   // of the plan's element-vector array, where the full call will write the same numbers again)

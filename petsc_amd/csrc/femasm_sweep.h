@@ -471,7 +471,7 @@ __device__ inline void row_contract(const double2 *__restrict__ recbuf, int mysl
 // steps of one row wave: wave index wv (0..2), row C (elastic) or third wv of the tile (Poisson)
 // Barrier among the three row waves only (the record wave keeps working): an LDS arrival counter that every
 // row wave bumps once per call and then polls.  All waves of a workgroup are resident, so the poll always
-// makes progress; the guard turns a logic error into a reported failure instead of a hung queue.
+// makes progress; the guard turns a logic error into a reported failure (FEMASM_ERR_HIP) instead of a hung queue.
 template <int NW = 3>
 __device__ inline void row_waves_sync(unsigned *cnt, unsigned &epoch, int lane, unsigned long long *bad) {
   epoch += NW;
@@ -479,8 +479,8 @@ __device__ inline void row_waves_sync(unsigned *cnt, unsigned &epoch, int lane, 
   if (lane == 0) atomicAdd(cnt, 1u);
   int guard = 0;
   while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch) {
-    if (++guard > (1 << 16)) {
-      if (lane == 0) atomicAdd(bad, 1ULL);
+    if (++guard > (1 << 20)) {  // ~0.1 s: cannot happen by design; reported as an internal error (flag 2)
+      if (lane == 0) atomicAdd(bad + 2, 1ULL);
       break;
     }
   }
