@@ -123,6 +123,7 @@ struct KArgs {
   int32_t mat_layout, mat_stride;
   int32_t bc;             // BC_* kind
   int32_t iface;          // 1: interface pass (elastic BC rows become zero rows)
+  int32_t zc;             // row-sweep kernels: node layers (rows in 2-D) per workgroup
 };
 
 // isotropic coefficient triple scaled by w*detJ, in the reference's operation order

@@ -400,7 +400,7 @@ struct RowSweep {
   static constexpr int EPASS = (NEL + 63) / 64;             // element passes of the record wave
   static constexpr int NRW = 1;  // record waves; 2 for Poisson was measured slower (2.17 vs 1.62 ms): the polling hand-shake costs more than it saves
 };
-constexpr int RS_ZC = 16;  // node layers per workgroup
+constexpr int RS_ZC = 16;  // default node layers per workgroup (KArgs::zc overrides)
 
 
 // contributions of the four elements of one element layer to row C of the lane's node.
@@ -583,8 +583,8 @@ __global__ __launch_bounds__(64 * (3 + RowSweep<KIND>::NRW), 2) void k_assemble_
   const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t M = s.dim[0], N = s.dim[1];
   const int64_t i0 = a.x0 + (int64_t)blockIdx.x * R_::TX, j0 = a.y0 + (int64_t)blockIdx.y * R_::TY;
-  const int64_t zc0 = a.s0 + (int64_t)blockIdx.z * RS_ZC;
-  const int64_t zc1 = (zc0 + RS_ZC < a.s1) ? zc0 + RS_ZC : a.s1;
+  const int64_t zc0 = a.s0 + (int64_t)blockIdx.z * a.zc;
+  const int64_t zc1 = (zc0 + a.zc < a.s1) ? zc0 + a.zc : a.s1;
   const int nz = (int)(zc1 - zc0);
   const int64_t L0 = zc0 - 1;
 
