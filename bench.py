@@ -158,15 +158,14 @@ def main():
         coords = synth.perturb_coords(coords, nsd, M, N, P, k0=cks)
     material = None
     E, nu = (90.0, 0.28) if wl == "elastic3d" else (1.0, 0.33)
-    if wl != "poisson3d" and not args.uniform_material:
-        if wl == "elastic3d":
-            material = synth.props_s3(M, N, P, coords, els, ele, ck0=cks, E=E, nu=nu)
-        else:
-            material = synth.props_e2(M, N, coords, els, ele, ck0=cks, E=E, nu=nu)
 
     plan = F.Plan(kind, M, N, P, coords=coords, ks=ks, ke=ke, cks=cks, cke=cke, device=local_rank)
     plan.set_stream(torch.cuda.current_stream().cuda_stream)
     plan.set_fast_path(args.fast_level)
+    if wl != "poisson3d" and not args.uniform_material:
+        # the drivers' GaussPointCoefficients fill (S3:1243-1363 / E2:618-670), on device (row N1)
+        material = torch.empty(plan.nel * stride, dtype=torch.float64, device=dev)
+        plan.fill_properties(material, E, nu, stride)
     vals = torch.empty(plan.nnz, dtype=torch.float64, device=dev)
     b = None if args.k_only else torch.empty(plan.nrows, dtype=torch.float64, device=dev)
 

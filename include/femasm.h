@@ -163,6 +163,13 @@ int femasm_interface_apply(femasm_plan *plan, const femasm_bc *bc, double *csr_v
 int femasm_compress_bc_rows(femasm_plan *plan, const femasm_bc *bc, const double *csr_values,
                             int64_t *rowptr_out, int32_t *colidx_out, double *values_out, int64_t *nnz_out);
 
+/* SURVEY 8(f) row N1, the step before the path: the drivers' fill of the GaussPointCoefficients array
+ * (S3:1243-1363 / R3:1254-1380: Gauss-point and face-Gauss-point positions, E, nu, body force and displacement
+ * gradient of the manufactured solution; E2:618-670: positions, E, nu, zero body force) for this slab's
+ * element layers [max(ks-1,0), ke-1), element index as in femasm_material with e_ks = that first layer.
+ * gp_out: HOST or DEVICE, nel*stride doubles; doubles beyond 400 (R3) are zeroed (enrich_type = 0). */
+int femasm_fill_properties(femasm_plan *plan, double E, double nu, int32_t stride, double *gp_out);
+
 /* SURVEY 8(f) row N3, the step after the solve: the element integrals of DMDAIntegrateErrors3D (P3:416-532,
  * S3:1041-1151) over this slab's elements against the drivers' manufactured solutions.  u: the solution on the
  * node layers [cks,cke) of the plan's coordinate array (the ghosted local vector of DMGlobalToLocal, P3:437),

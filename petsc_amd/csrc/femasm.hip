@@ -746,6 +746,31 @@ int femasm_assemble_interface(femasm_plan *p, const femasm_material *mat, const 
   return FEMASM_OK;
 }
 
+int femasm_fill_properties(femasm_plan *p, double E, double nu, int32_t stride, double *gp_out) {
+  if (!p || !gp_out) return fail(FEMASM_ERR_ARG, "null argument");
+  if (p->kind == KIND_POISSON) return fail(FEMASM_ERR_ARG, "the Poisson driver has no property array");
+  const int need = (p->kind == KIND_PLANE) ? 24 : 400;
+  if (stride < need || stride > 416) return fail(FEMASM_ERR_ARG, "stride %d not in [%d, 416]", stride, need);
+  HIPCHK(hipSetDevice(p->device));
+  if (p->nel <= 0) return FEMASM_OK;
+  const size_t bytes = (size_t)p->nel * stride * sizeof(double);
+  double *d_out = gp_out;
+  const bool host = !is_device_ptr(gp_out);
+  if (host) HIPCHK(hipMalloc(&d_out, bytes));
+  if (p->kind == KIND_ELASTIC)
+    hipLaunchKernelGGL(k_fill_props_s3, dim3(nblk(p->nel, 8)), dim3(256), 0, p->stream, p->s, p->coords, E, nu, stride,
+                       p->nel, d_out);
+  else
+    hipLaunchKernelGGL(k_fill_props_e2, dim3(nblk(p->nel)), dim3(256), 0, p->stream, p->s, p->coords, E, nu, stride,
+                       p->nel, d_out);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && host) e = hipMemcpyAsync(gp_out, d_out, bytes, hipMemcpyDeviceToHost, p->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+  if (host) (void)hipFree(d_out);
+  if (e != hipSuccess) return fail(FEMASM_ERR_HIP, "femasm_fill_properties: %s", hipGetErrorString(e));
+  return FEMASM_OK;
+}
+
 int femasm_error_integrals(femasm_plan *p, const double *u, double sums[2]) {
   if (!p || !u || !sums) return fail(FEMASM_ERR_ARG, "null argument");
   if (p->kind == KIND_PLANE) return fail(FEMASM_ERR_ARG, "the reference has no error norms for the 2-D driver");

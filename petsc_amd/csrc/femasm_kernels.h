@@ -1010,6 +1010,106 @@ __global__ __launch_bounds__(256) void k_iface_apply(const Slab s, int bc, doubl
 }
 
 // ---------------------------------------------------------------------------
+// N1: fill of the GaussPointCoefficients array on device (the step before the path; S3:1243-1363, E2:618-670).
+// S3: 32 lanes per element, lane q < 24 = face Gauss point q (position, E_B, nu_B, grad u of the manufactured
+// solution), lane q >= 24 = volume Gauss point q-24 (position, E, nu, body force); the 400 doubles of a record
+// are gathered in LDS and written as whole 128-byte lines.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fill_props_s3(const Slab s, const double *coords, double E, double nu,
+                                                       int stride, int64_t nel, double *gp) {
+  __shared__ __attribute__((aligned(16))) double sh_q[8][416];
+  __shared__ double sh_xc[8][24];
+  constexpr double PI = 3.14159265358979323846264338327950288;
+  const int tid = threadIdx.x, el = tid >> 5, q = tid & 31;
+  const int64_t M = s.dim[0], N = s.dim[1];
+  const int64_t mx = M - 1, my = N - 1;
+  const int64_t e = (int64_t)blockIdx.x * 8 + el;
+  const bool live = e < nel;
+  if (live && q < 24) {
+    const int64_t ex = e % mx, ey = (e / mx) % my, ez = s.els + e / (mx * my);
+    const int n = q / 3, d = q % 3;
+    const int64_t node = (ex + HDI[n]) + M * ((ey + HDJ[n]) + N * (ez + HDK[n] - s.cks));
+    sh_xc[el][q] = coords[3 * node + d];
+  }
+  __syncthreads();
+  if (live) {
+    const double *xc = sh_xc[el];
+    double *o = sh_q[el];
+    const double *Nn = (q < 24) ? c_tab3.NF[q] : c_tab3.N[q - 24];
+    double x = 0.0, y = 0.0, z = 0.0;
+#pragma unroll
+    for (int n = 0; n < 8; n++) {
+      x = x + Nn[n] * xc[3 * n];
+      y = y + Nn[n] * xc[3 * n + 1];
+      z = z + Nn[n] * xc[3 * n + 2];
+    }
+    if (q < 24) {
+      o[24 + 3 * q] = x; o[24 + 3 * q + 1] = y; o[24 + 3 * q + 2] = z;
+      o[112 + q] = E;
+      o[136 + q] = nu;
+#pragma unroll
+      for (int c = 0; c < 3; c++) { o[184 + 3 * q + c] = 0.0; o[256 + 3 * q + c] = 0.0; }
+      o[328 + 3 * q] = PI * cos(PI * x) * sin(PI * y) * sin(PI * z);
+      o[328 + 3 * q + 1] = PI * sin(PI * x) * cos(PI * y) * sin(PI * z);
+      o[328 + 3 * q + 2] = PI * sin(PI * x) * sin(PI * y) * cos(PI * z);
+    } else {
+      const int p = q - 24;
+      o[3 * p] = x; o[3 * p + 1] = y; o[3 * p + 2] = z;
+      o[96 + p] = E;
+      o[104 + p] = nu;
+      const double den = 2 * nu * nu + nu - 1;
+      o[160 + p] = (E * PI * PI * cos(PI * x) * cos(PI * z) * sin(PI * y)) / (2 * den);
+      o[168 + p] = (E * PI * PI * cos(PI * y) * sin(PI * x) * cos(PI * z)) / (2 * den);
+      o[176 + p] = (E * PI * PI * sin(PI * x) * sin(PI * y) * sin(PI * z) * (3 * nu - 2)) / den;
+    }
+    for (int t = 400 + q; t < stride; t += 32) o[t] = 0.0;  // R3: enrich_type / n_enrich = 0
+  }
+  __syncthreads();
+  if (live) {
+    double *dst = gp + e * (int64_t)stride;
+    if ((stride & 1) == 0) {
+      for (int k = q; k < stride / 2; k += 32)
+        reinterpret_cast<double2 *>(dst)[k] = reinterpret_cast<const double2 *>(sh_q[el])[k];
+    } else {
+      for (int k = q; k < stride; k += 32) dst[k] = sh_q[el][k];
+    }
+  }
+}
+
+// E2: one thread per element (24 doubles: Gauss point positions, E, nu, zero body force)
+__global__ __launch_bounds__(256) void k_fill_props_e2(const Slab s, const double *coords, double E, double nu,
+                                                       int stride, int64_t nel, double *gp) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= nel) return;
+  const int64_t M = s.dim[0], mx = M - 1;
+  const int64_t ex = e % mx, ey = s.els + e / mx;
+  double xc[8];
+#pragma unroll
+  for (int n = 0; n < 4; n++) {
+    const int64_t node = (ex + QDI[n]) + M * (ey + QDJ[n] - s.cks);
+    xc[2 * n] = coords[2 * node];
+    xc[2 * n + 1] = coords[2 * node + 1];
+  }
+  double *o = gp + e * (int64_t)stride;
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    double gx = 0.0, gy = 0.0;
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+      gx = gx + c_tab2.N[p][n] * xc[2 * n];
+      gy = gy + c_tab2.N[p][n] * xc[2 * n + 1];
+    }
+    o[2 * p] = gx;
+    o[2 * p + 1] = gy;
+    o[8 + p] = E;
+    o[12 + p] = nu;
+    o[16 + p] = 0.0;
+    o[20 + p] = 0.0;
+  }
+  for (int t = 24; t < stride; t++) o[t] = 0.0;
+}
+
+// ---------------------------------------------------------------------------
 // N3: error integrals against the manufactured solutions (DMDAIntegrateErrors3D, P3:416-532, S3:1041-1151):
 // per element  sum_p w detJ sum_i N_i e_i^2  and  sum_p w detJ sum_i |grad N_i|^2 e_i^2  with e = nodal error
 // (the reference's nodal form).  One thread per element, fixed-order tree per workgroup -> partial[2*block],

@@ -30,7 +30,7 @@ EXPORTS = [
     "femasm_plan_create", "femasm_plan_destroy", "femasm_plan_set_stream", "femasm_pattern",
     "femasm_pattern_copy", "femasm_scatter_map", "femasm_assemble_system", "femasm_interface_buffers",
     "femasm_interface_set_buffers", "femasm_interface_apply", "femasm_compress_bc_rows", "femasm_plan_sync", "femasm_last_error",
-    "femasm_version", "femasm_plan_set_fast_path", "femasm_plan_get_fast_path", "femasm_assemble_interface", "femasm_error_integrals",
+    "femasm_version", "femasm_plan_set_fast_path", "femasm_plan_get_fast_path", "femasm_assemble_interface", "femasm_error_integrals", "femasm_fill_properties",
 ]
 
 
@@ -208,6 +208,10 @@ class Plan:
     def interface_apply(self, values, b, bc=BC_NONE):
         bcs = BC(bc, 0)
         _check(load().femasm_interface_apply(self._h, C.byref(bcs), _ptr(values), _ptr(b)))
+
+    def fill_properties(self, out, E, nu, stride):
+        """N1: the drivers' GaussPointCoefficients fill for this slab's element layers, into `out`."""
+        _check(load().femasm_fill_properties(self._h, C.c_double(E), C.c_double(nu), C.c_int32(stride), _ptr(out)))
 
     def error_integrals(self, u):
         """(sum of L2 integrals, sum of H1 integrals) over this slab's elements; u on the plan's coordinate layers."""

@@ -446,3 +446,67 @@ def test_error_integrals_add_up_over_slabs(env):
         tot += plan.error_integrals(ul)  # the MPI_Allreduce of S3:1137-1138
         plan.close()
     assert abs(np.sqrt(tot[0]) - l2) <= 1e-12 * l2 and abs(np.sqrt(tot[1]) - h1) <= 1e-12 * h1
+
+
+# ---- N1: GaussPointCoefficients fill on device ----
+@pytest.mark.parametrize("stride", [400, 416])
+@pytest.mark.parametrize("host", [False, True])
+def test_fill_properties_s3_matches_the_driver_fill(env, stride, host):
+    torch, F, dev, O = env["torch"], env["F"], env["dev"], env["O"]
+    M, N, P = 6, 5, 7
+    coords = O.perturb_coords(O.uniform_coords(3, M, N, P), 3, M, N, P)
+    ref = O.props_s3(M - 1, N - 1, P - 1, coords, E=90.0, nu=0.28, stride=stride).reshape(-1, stride)
+    plan = F.Plan(F.ELASTIC3D_Q1, M, N, P, coords=torch.from_numpy(coords).to(dev))
+    if host:
+        out = np.full(ref.size, np.nan)
+        plan.fill_properties(out, 90.0, 0.28, stride)
+    else:
+        t = torch.full((ref.size,), float("nan"), dtype=torch.float64, device=dev)
+        plan.fill_properties(t, 90.0, 0.28, stride)
+        out = t.cpu().numpy()
+    out = out.reshape(-1, stride)
+    assert not np.isnan(out).any()
+    assert np.array_equal(out[:, 96:160], ref[:, 96:160])    # E, nu, E_B, nu_B: copies
+    assert np.array_equal(out[:, 400:], ref[:, 400:])        # R3 tail: zeros
+    for lo, hi in ((0, 96), (160, 184), (184, 400)):         # positions; body force; displacement gradient
+        assert rel(out[:, lo:hi], ref[:, lo:hi]) <= TOL
+    # and the system assembled from the device-filled array is the oracle's system
+    rp, ci = O.pattern(3, 3, M, N, P)
+    K, b = O.assemble_elastic3d(M, N, P, coords, ref.reshape(-1).copy() if stride == 400 else
+                                O.props_s3(M - 1, N - 1, P - 1, coords), rp, ci)
+    O.bc_s3(M, N, P, coords, rp, ci, K, b)
+    vals = torch.empty(plan.nnz, dtype=torch.float64, device=dev)
+    bb = torch.empty(plan.nrows, dtype=torch.float64, device=dev)
+    plan.assemble_system(vals, bb, material=torch.from_numpy(out.reshape(-1).copy()).to(dev), stride=stride,
+                         bc=F.BC_S3_ALLFACES_EXACT)
+    assert rel(vals.cpu().numpy(), K) <= TOL and rel(bb.cpu().numpy(), b) <= TOL
+    plan.close()
+
+
+def test_fill_properties_e2_matches_the_driver_fill(env):
+    torch, F, dev, O = env["torch"], env["F"], env["dev"], env["O"]
+    M, N = 23, 11
+    coords = O.perturb_coords(O.uniform_coords(2, M, N), 2, M, N)
+    ref = O.props_e2(M - 1, N - 1, coords, E=1.0, nu=0.33).reshape(-1, 24)
+    plan = F.Plan(F.PLANE_STRAIN2D_Q1, M, N, 1, coords=torch.from_numpy(coords).to(dev))
+    t = torch.full((ref.size,), float("nan"), dtype=torch.float64, device=dev)
+    plan.fill_properties(t, 1.0, 0.33, 24)
+    out = t.cpu().numpy().reshape(-1, 24)
+    assert np.array_equal(out[:, 8:], ref[:, 8:]) and rel(out[:, :8], ref[:, :8]) <= TOL
+    plan.close()
+
+
+def test_fill_properties_of_a_slab_uses_its_element_layers(env):
+    torch, F, dev, O, slab = env["torch"], env["F"], env["dev"], env["O"], env["slab"]
+    M, N, P = 5, 4, 9
+    coords = O.perturb_coords(O.uniform_coords(3, M, N, P), 3, M, N, P)
+    ref = O.props_s3(M - 1, N - 1, P - 1, coords).reshape(P - 1, -1)
+    for (ks, ke) in slab.slab_ranges(P, 3):
+        cks, cke = max(ks - 1, 0), min(ke + 1, P)
+        els, ele = slab.element_range(ks, ke)
+        co = torch.from_numpy(coords.reshape(P, -1)[cks:cke].reshape(-1).copy()).to(dev)
+        plan = F.Plan(F.ELASTIC3D_Q1, M, N, P, coords=co, ks=ks, ke=ke, cks=cks, cke=cke)
+        t = torch.empty((ele - els) * ref.shape[1], dtype=torch.float64, device=dev)
+        plan.fill_properties(t, 90.0, 0.28, 400)
+        assert rel(t.cpu().numpy(), ref[els:ele].reshape(-1)) <= TOL
+        plan.close()
