@@ -163,6 +163,14 @@ int femasm_interface_apply(femasm_plan *plan, const femasm_bc *bc, double *csr_v
 int femasm_compress_bc_rows(femasm_plan *plan, const femasm_bc *bc, const double *csr_values,
                             int64_t *rowptr_out, int32_t *colidx_out, double *values_out, int64_t *nnz_out);
 
+/* y = K x without forming K, from the same element arithmetic (any hexahedra / quads,
+ * (E,nu) per Gauss point), Dirichlet rows as in the assembled matrix (row = diag * e_row, no column
+ * elimination).  x: DEVICE vector on the node layers [cks,cke) of the plan's coordinate array; y: DEVICE, the
+ * owned rows.  On a slab with ks > 0 the partial y of node layer ks-1 is left in the b part of the send buffer:
+ * exchange it and call femasm_interface_apply(plan, bc, NULL, y), as after an assembly.  Deterministic. */
+int femasm_apply_operator(femasm_plan *plan, const femasm_material *material, const femasm_bc *bc, const double *x,
+                          double *y);
+
 /* SURVEY 8(f) row N1, the step before the path: the drivers' fill of the GaussPointCoefficients array
  * (S3:1243-1363 / R3:1254-1380: Gauss-point and face-Gauss-point positions, E, nu, body force and displacement
  * gradient of the manufactured solution; E2:618-670: positions, E, nu, zero body force) for this slab's

@@ -746,6 +746,74 @@ int femasm_assemble_interface(femasm_plan *p, const femasm_material *mat, const 
   return FEMASM_OK;
 }
 
+int femasm_apply_operator(femasm_plan *p, const femasm_material *mat, const femasm_bc *bcs, const double *x,
+                          double *y) {
+  if (!p || !x || !y) return fail(FEMASM_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(p->device));
+  const int bc = bcs ? bcs->kind : FEMASM_BC_NONE;
+  if (bc < 0 || bc > 3) return fail(FEMASM_ERR_ARG, "unknown bc kind %d", bc);
+  if ((bc == FEMASM_BC_POISSON_INLOOP && p->kind != KIND_POISSON) ||
+      (bc == FEMASM_BC_E2_COMPRESSION && p->kind != KIND_PLANE) ||
+      (bc == FEMASM_BC_S3_ALLFACES_EXACT && p->kind != KIND_ELASTIC))
+    return fail(FEMASM_ERR_ARG, "bc kind %d does not belong to problem kind %d", bc, p->kind);
+  femasm_material mloc{};
+  mloc.layout = FEMASM_MAT_UNIFORM;
+  if (p->kind != KIND_POISSON) {
+    if (!mat) return fail(FEMASM_ERR_ARG, "material is required for elastic problems");
+    mloc = *mat;
+    if (mloc.layout == FEMASM_MAT_AOS) {
+      const int need = (p->kind == KIND_PLANE) ? 24 : 400;
+      if (!mloc.gp || !is_device_ptr(mloc.gp) || mloc.stride < need || mloc.e_ks > p->s.els)
+        return fail(FEMASM_ERR_ARG, "femasm_apply_operator needs a device material array covering the slab's elements");
+    } else if (mloc.layout != FEMASM_MAT_UNIFORM) {
+      return fail(FEMASM_ERR_ARG, "unknown material layout %d", mloc.layout);
+    }
+    p->s.mat_e_ks = (mloc.layout == FEMASM_MAT_AOS) ? mloc.e_ks : p->s.els;
+  }
+  if (!is_device_ptr(x) || !is_device_ptr(y)) return fail(FEMASM_ERR_ARG, "femasm_apply_operator works on device vectors");
+  const Slab &s = p->s;
+  RArgs a{};
+  a.coords = p->coords;
+  a.gp = (mloc.layout == FEMASM_MAT_AOS) ? mloc.gp : nullptr;
+  a.elemF = p->elemF;
+  a.nelp = (p->nel + 15) & ~(int64_t)15;
+  a.cke = p->cke;
+  a.nel = p->nel;
+  a.mat_layout = mloc.layout;
+  a.mat_stride = mloc.stride;
+  a.bc = bc;
+  a.bad = p->bad;
+  a.x = x;
+  if (p->nel > 0) {
+    switch (p->kind) {
+      case KIND_POISSON: hipLaunchKernelGGL(k_op_elem<KIND_POISSON>, dim3(nblk(p->nel)), dim3(256), 0, p->stream, s, a, 0.0, 0.0); break;
+      case KIND_PLANE:   hipLaunchKernelGGL(k_op_elem<KIND_PLANE>, dim3(nblk(p->nel)), dim3(256), 0, p->stream, s, a, mloc.E, mloc.nu); break;
+      case KIND_ELASTIC: hipLaunchKernelGGL(k_op_elem<KIND_ELASTIC>, dim3(nblk(p->nel)), dim3(256), 0, p->stream, s, a, mloc.E, mloc.nu); break;
+    }
+    HIPCHK(hipGetLastError());
+  }
+  auto gather = [&](double *out, int64_t s0, int64_t s1, int iface) {
+    if (s1 <= s0) return;
+    RArgs g = a;
+    g.out = out;
+    g.s0 = s0;
+    g.s1 = s1;
+    g.iface = iface;
+    const dim3 grid = (s.nsd == 3) ? dim3(nblk(s.dim[0]), (unsigned)s.dim[1], (unsigned)(s1 - s0))
+                                   : dim3(nblk(s.dim[0]), (unsigned)(s1 - s0), 1);
+    switch (p->kind) {
+      case KIND_POISSON: hipLaunchKernelGGL(k_rhs_gather<KIND_POISSON>, grid, dim3(256), 0, p->stream, s, g); break;
+      case KIND_PLANE:   hipLaunchKernelGGL(k_rhs_gather<KIND_PLANE>, grid, dim3(256), 0, p->stream, s, g); break;
+      case KIND_ELASTIC: hipLaunchKernelGGL(k_rhs_gather<KIND_ELASTIC>, grid, dim3(256), 0, p->stream, s, g); break;
+    }
+  };
+  gather(y, s.ks, s.ke, 0);
+  if (s.ks > 0 && p->send) gather(p->send + p->send_nnz, s.ks - 1, s.ks, 1);  // partial rows owed to the rank below
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(p->stream));
+  return FEMASM_OK;
+}
+
 int femasm_fill_properties(femasm_plan *p, double E, double nu, int32_t stride, double *gp_out) {
   if (!p || !gp_out) return fail(FEMASM_ERR_ARG, "null argument");
   if (p->kind == KIND_POISSON) return fail(FEMASM_ERR_ARG, "the Poisson driver has no property array");

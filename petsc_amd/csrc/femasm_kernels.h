@@ -585,6 +585,7 @@ struct RArgs {
   int32_t mat_layout, mat_stride;
   int32_t bc, iface;
   unsigned long long *bad;  // plan flags / profiling counters
+  const double *x;          // N4 operator apply: input vector on the node layers of coords (else null)
 };
 
 template <int KIND>
@@ -913,6 +914,119 @@ __global__ __launch_bounds__(256) void k_rhs_elem_elastic_coop(const Slab s, con
 }
 
 // ---------------------------------------------------------------------------
+// N4: matrix-free operator apply, pass 1: one thread per element computes f_e = Ke x_e without forming Ke
+// (per Gauss point: displacement gradient H = sum_b x_b grad N_b^T, stress from the w*detJ-scaled D11/D12/D44,
+// f_a = sigma grad N_a; Poisson: f_a = w detJ grad N_a . sum_b x_b grad N_b) into the element-vector array;
+// pass 2 is k_rhs_gather (same order of summation as the assembled rows' element contributions).
+// ---------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(256) void k_op_elem(const Slab s, const RArgs a, double Eu, double nuu) {
+  using T = Traits<KIND>;
+  constexpr int NSD = T::NSD, DOF = T::DOF, NEN = T::NEN, NGP = T::NGP;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= a.nel) return;
+  const int64_t M = s.dim[0], N = s.dim[1];
+  const int64_t mx = M - 1, my = N - 1;
+  double xc[NEN * NSD], xe[NEN * DOF], F[NEN * DOF];
+  int64_t emat;
+  if constexpr (NSD == 3) {
+    const int64_t ex = e % mx, ey = (e / mx) % my, ez = s.els + e / (mx * my);
+    emat = ex + mx * (ey + my * (ez - s.mat_e_ks));
+#pragma unroll
+    for (int n = 0; n < 8; n++) {
+      const int64_t node = (ex + HDI[n]) + M * ((ey + HDJ[n]) + N * (ez + HDK[n] - s.cks));
+#pragma unroll
+      for (int d = 0; d < 3; d++) xc[3 * n + d] = a.coords[3 * node + d];
+#pragma unroll
+      for (int c = 0; c < DOF; c++) xe[n * DOF + c] = a.x[node * DOF + c];
+    }
+  } else {
+    const int64_t ex = e % mx, ey = s.els + e / mx;
+    emat = ex + mx * (ey - s.mat_e_ks);
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+      const int64_t node = (ex + QDI[n]) + M * (ey + QDJ[n] - s.cks);
+#pragma unroll
+      for (int d = 0; d < 2; d++) xc[2 * n + d] = a.coords[2 * node + d];
+#pragma unroll
+      for (int c = 0; c < DOF; c++) xe[n * DOF + c] = a.x[node * DOF + c];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NEN * DOF; q++) F[q] = 0.0;
+  for (int p = 0; p < NGP; p++) {
+    double g[NEN][NSD], wJ;
+    if constexpr (NSD == 3) {
+      const double(*G)[8] = c_tab3.G[p];
+      const Jac3 jj = jac3(G, xc);
+#pragma unroll
+      for (int n = 0; n < 8; n++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) g[n][k] = G[0][n] * jj.iJ[k][0] + G[1][n] * jj.iJ[k][1] + G[2][n] * jj.iJ[k][2];
+      wJ = 1.0 * jj.det;
+    } else {
+      const double(*G)[4] = c_tab2.G[p];
+      const Jac2 jj = jac2(G, xc);
+#pragma unroll
+      for (int n = 0; n < 4; n++) {
+        g[n][0] = G[0][n] * jj.i00 + G[1][n] * jj.i01;
+        g[n][1] = G[0][n] * jj.i10 + G[1][n] * jj.i11;
+      }
+      wJ = 1.0 * jj.det;
+    }
+    if constexpr (KIND == KIND_POISSON) {
+      double gu[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+      for (int n = 0; n < 8; n++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) gu[k] += g[n][k] * xe[n];
+#pragma unroll
+      for (int n = 0; n < 8; n++) F[n] += wJ * (g[n][0] * gu[0] + g[n][1] * gu[1] + g[n][2] * gu[2]);
+    } else {
+      double E = Eu, nu = nuu;
+      if (a.mat_layout == 0) {
+        constexpr int offE = (KIND == KIND_PLANE) ? 8 : 96, offNu = (KIND == KIND_PLANE) ? 12 : 104;
+        const double *q = a.gp + emat * a.mat_stride;
+        E = q[offE + p];
+        nu = q[offNu + p];
+      }
+      double d11, d12, d44;
+      scaled_coefs<KIND>(E, nu, wJ, d11, d12, d44);
+      double H[NSD][NSD];  // H[i][j] = d u_i / d x_j
+#pragma unroll
+      for (int i = 0; i < NSD; i++)
+#pragma unroll
+        for (int j = 0; j < NSD; j++) {
+          double v = 0.0;
+#pragma unroll
+          for (int n = 0; n < NEN; n++) v += xe[n * DOF + i] * g[n][j];
+          H[i][j] = v;
+        }
+      double sg[NSD][NSD];
+      double tr = 0.0;
+#pragma unroll
+      for (int i = 0; i < NSD; i++) tr += H[i][i];
+#pragma unroll
+      for (int i = 0; i < NSD; i++)
+#pragma unroll
+        for (int j = 0; j < NSD; j++)
+          sg[i][j] = (i == j) ? d11 * H[i][i] + d12 * (tr - H[i][i]) : d44 * (H[i][j] + H[j][i]);
+#pragma unroll
+      for (int n = 0; n < NEN; n++)
+#pragma unroll
+        for (int i = 0; i < NSD; i++) {
+          double v = 0.0;
+#pragma unroll
+          for (int j = 0; j < NSD; j++) v += sg[i][j] * g[n][j];
+          F[n * DOF + i] += v;
+        }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NEN * DOF; q++) a.elemF[q * a.nelp + e] = F[q];
+}
+
+// ---------------------------------------------------------------------------
 // RHS, pass 2: one thread per node; contributions added in the reference's element
 // order (k -> j -> i) (S3: Fe + Ge of an element enter as one term); then the Dirichlet value.
 // ---------------------------------------------------------------------------
@@ -965,6 +1079,17 @@ __global__ __launch_bounds__(256) void k_rhs_gather(const Slab s, const RArgs a)
       // partial sums owed to the rank below: Dirichlet rows are ignored by the receiver
 #pragma unroll
       for (int c = 0; c < DOF; c++) b[c] = 0.0;
+    } else if (a.x) {
+      // operator apply: a Dirichlet row is diag * e_row (diag 1; Poisson: valence of the assembled elements)
+      double diag = 1.0;
+      if (a.bc == BC_POISSON) {
+        const int vx = (i > 0) + (i < M - 1), vy = (j > 0) + (j < N - 1);
+        const int vz = (k - 1 >= s.els && k - 1 < s.ele) + (k >= s.els && k < s.ele);
+        diag = (double)(vx * vy * vz);
+      }
+      const int64_t node = (NSD == 3) ? i + M * (j + N * (k - s.cks)) : i + M * (j - s.cks);
+#pragma unroll
+      for (int c = 0; c < DOF; c++) b[c] = diag * a.x[node * DOF + c];
     } else if (a.bc == BC_POISSON) {
       b[0] = 0.0;                                   // P3:624-630
     } else if (a.bc == BC_E2) {

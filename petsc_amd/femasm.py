@@ -30,7 +30,7 @@ EXPORTS = [
     "femasm_plan_create", "femasm_plan_destroy", "femasm_plan_set_stream", "femasm_pattern",
     "femasm_pattern_copy", "femasm_scatter_map", "femasm_assemble_system", "femasm_interface_buffers",
     "femasm_interface_set_buffers", "femasm_interface_apply", "femasm_compress_bc_rows", "femasm_plan_sync", "femasm_last_error",
-    "femasm_version", "femasm_plan_set_fast_path", "femasm_plan_get_fast_path", "femasm_assemble_interface", "femasm_error_integrals", "femasm_fill_properties",
+    "femasm_version", "femasm_plan_set_fast_path", "femasm_plan_get_fast_path", "femasm_assemble_interface", "femasm_error_integrals", "femasm_fill_properties", "femasm_apply_operator",
 ]
 
 
@@ -208,6 +208,15 @@ class Plan:
     def interface_apply(self, values, b, bc=BC_NONE):
         bcs = BC(bc, 0)
         _check(load().femasm_interface_apply(self._h, C.byref(bcs), _ptr(values), _ptr(b)))
+
+    def apply_operator(self, x, y, material=None, bc=BC_NONE, E=0.0, nu=0.0, stride=0, e_ks=None):
+        """N4: y = K x matrix-free (device tensors; x on the plan's coordinate layers, y the owned rows)."""
+        if material is None:
+            mat = Material(MAT_UNIFORM, 0, 0, None, E, nu)
+        else:
+            mat = Material(MAT_AOS, stride, self.els if e_ks is None else e_ks, _ptr(material), E, nu)
+        bcs = BC(bc, 0)
+        _check(load().femasm_apply_operator(self._h, C.byref(mat), C.byref(bcs), _ptr(x), _ptr(y)))
 
     def fill_properties(self, out, E, nu, stride):
         """N1: the drivers' GaussPointCoefficients fill for this slab's element layers, into `out`."""

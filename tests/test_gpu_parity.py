@@ -510,3 +510,56 @@ def test_fill_properties_of_a_slab_uses_its_element_layers(env):
         plan.fill_properties(t, 90.0, 0.28, 400)
         assert rel(t.cpu().numpy(), ref[els:ele].reshape(-1)) <= TOL
         plan.close()
+
+
+# ---- N4: matrix-free operator apply ----
+@pytest.mark.parametrize("kind,dims", [("p3", (7, 6, 8)), ("e2", (31, 17)), ("s3", (6, 7, 5))])
+def test_operator_apply_equals_the_assembled_matrix_times_x(env, kind, dims):
+    import scipy.sparse as sp
+    torch, F, dev = env["torch"], env["F"], env["dev"]
+    case = make_case(env, kind, dims, perturb=True, vary_material=(kind != "p3"))
+    M, N, P = case["dims"]
+    n = len(case["rp"]) - 1
+    K = sp.csr_matrix((case["K"], case["ci"], case["rp"]), shape=(n, n))
+    x = np.random.default_rng(2).uniform(-1, 1, size=n)
+    plan = F.Plan(case["problem"], M, N, P, coords=torch.from_numpy(case["coords"]).to(dev))
+    y = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
+    mat = None if case["props"] is None else torch.from_numpy(case["props"]).to(dev)
+    plan.apply_operator(torch.from_numpy(x).to(dev), y, material=mat, stride=case["stride"], bc=case["bc"])
+    assert rel(y.cpu().numpy(), K @ x) <= 1e-12
+    plan.close()
+
+
+def test_operator_apply_over_slabs_with_the_interface_exchange(env):
+    import scipy.sparse as sp
+    torch, F, dev, slab = env["torch"], env["F"], env["dev"], env["slab"]
+    case = make_case(env, "s3", (5, 4, 10), perturb=True, vary_material=True)
+    M, N, P = case["dims"]
+    n = len(case["rp"]) - 1
+    K = sp.csr_matrix((case["K"], case["ci"], case["rp"]), shape=(n, n))
+    x = np.random.default_rng(4).uniform(-1, 1, size=n)
+    plane_e, plane_n = (M - 1) * (N - 1), M * N * 3
+    ranges = slab.slab_ranges(P, 3)
+    plans, ys, bufs = [], [], []
+    for (ks, ke) in ranges:
+        cks, cke = max(ks - 1, 0), min(ke + 1, P)
+        els, ele = slab.element_range(ks, ke)
+        co = torch.from_numpy(case["coords"].reshape(P, -1)[cks:cke].reshape(-1).copy()).to(dev)
+        xl = torch.from_numpy(x.reshape(P, -1)[cks:cke].reshape(-1).copy()).to(dev)
+        mat = torch.from_numpy(case["props"].reshape(-1, plane_e * 400)[els:ele].reshape(-1).copy()).to(dev)
+        plan = F.Plan(F.ELASTIC3D_Q1, M, N, P, coords=co, ks=ks, ke=ke, cks=cks, cke=cke)
+        (_, sc), (_, rc) = plan.interface_buffers()
+        send = torch.zeros(max(sc, 1), dtype=torch.float64, device=dev)
+        recv = torch.zeros(max(rc, 1), dtype=torch.float64, device=dev)
+        plan.interface_set_buffers(send if sc else None, recv if rc else None)
+        y = torch.full((plan.nrows,), float("nan"), dtype=torch.float64, device=dev)
+        plan.apply_operator(xl, y, material=mat, stride=400, bc=case["bc"], e_ks=els)
+        plans.append(plan); ys.append(y); bufs.append((send, recv, sc, rc))
+    for r in range(len(ranges) - 1):
+        bufs[r][1][:bufs[r][3]].copy_(bufs[r + 1][0][:bufs[r + 1][2]])
+    for r in range(len(ranges)):
+        plans[r].interface_apply(None, ys[r], bc=case["bc"])
+    y = np.concatenate([t.cpu().numpy() for t in ys])
+    assert rel(y, K @ x) <= 1e-12
+    for p in plans:
+        p.close()
