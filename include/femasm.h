@@ -103,14 +103,15 @@ int femasm_plan_set_stream(femasm_plan *plan, void *stream);
 
 /* No counterpart in the reference (an optimisation switch of this engine).  Every kind
  * has a specialised stiffness kernel besides the general one:
- *   level 2  elastic (2-D and 3-D): axis-aligned box / rectangle elements (what
- *            DMDASetUniformCoordinates P3:663 / E2:577 / S3:1198 produces) with one (E,nu)
- *            per element; Poisson: as level 1
+ *   level 2  rectilinear mesh (x depends on i only, y on j, z on k: what DMDASetUniformCoordinates
+ *            P3:663 / E2:577 / S3:1198 produces; every element an axis-aligned box) with one
+ *            (E,nu) per element
  *   level 1  Poisson: affine elements (parallelepipeds); elastic: as level 0
  *   level 0  general isoparametric elements, (E,nu) per Gauss point
- * The specialised kernel tests its premise on every element it touches, exactly (bitwise-equal
- * edge vectors and material); on any failure femasm_assemble_system reassembles K with the
- * general kernel and the plan stays at level 0.  Default 2.  Results differ by rounding only. */
+ * The premise is tested exactly on every node / element touched (bitwise-equal coordinates, edge
+ * vectors and material); on any failure femasm_assemble_system reassembles K one level down
+ * (Poisson 2 -> 1 -> 0, elastic 2 -> 0) and the plan stays there.  Default 2.  Results of the
+ * levels differ by rounding only. */
 int femasm_plan_set_fast_path(femasm_plan *plan, int level);
 int femasm_plan_get_fast_path(femasm_plan *plan, int *level);
 

@@ -211,7 +211,9 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
         const bool aos3 = (KIND != KIND_POISSON) && mat && mat->layout == FEMASM_MAT_AOS;
         const double nint = (double)(M - 2) * (double)(N - 2) * (double)(z1 - z0);  // interior nodes = rows / dof
         // stores of the interior rows + one read of the coordinates and of E,nu at the Gauss points
-        p->bytes_main = 8.0 * nint * 27.0 * T::DOF * T::DOF + 8.0 * T::NSD * (double)M * N * (z1 - z0 + 2) +
+        // (at level 2 the coordinates are read by the rectilinearity pre-pass, not by this kernel)
+        p->bytes_main = 8.0 * nint * 27.0 * T::DOF * T::DOF +
+                        (p->fast_level == 2 ? 0.0 : 8.0 * T::NSD * (double)M * N * (z1 - z0 + 2)) +
                         (aos3 ? 16.0 * T::NGP * (double)(M - 1) * (N - 1) * (z1 - z0 + 1) : 0.0);
       }
       if (fast) {
@@ -220,8 +222,15 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
         // prologue of a workgroup costs about one step); FEMASM_ZC overrides for experiments
         int64_t zc = 32;
         if (const char *e = getenv("FEMASM_ZC")) zc = atoi(e) > 0 ? atoi(e) : zc;
+        if (zc > 128) zc = 128;
         KArgs az = a;
         az.zc = (int32_t)zc;
+        az.rect = (p->fast_level == 2) ? 1 : 0;
+        if (az.rect) {  // level 2: geometry from three coordinate lines, after an exact test that the mesh is rectilinear
+          const int64_t nlayers = p->cke - p->s.cks;
+          hipLaunchKernelGGL(k_check_rectilinear, dim3(nblk(M), (unsigned)N, (unsigned)nlayers), dim3(256), 0, p->stream,
+                             p->s, p->coords, nlayers, p->bad + 1);
+        }
         dim3 grid((unsigned)((b.x1 - b.x0 + TX - 1) / TX), (unsigned)((b.y1 - b.y0 + TY - 1) / TY),
                   (unsigned)((z1 - z0 + zc - 1) / zc));
         hipLaunchKernelGGL(k_assemble_rowsweep<KIND>, grid, dim3(64 * (3 + RowSweep<KIND>::NRW)), 0, p->stream, p->s, az);
@@ -615,12 +624,12 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
     ms_staging += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
   double k_ms_redo = -1.0;
-  if (d_vals && p->used_fast && flags[1]) {
-    // The fast kernel verifies its own premise on every element (elastic: axis-aligned box,
-    // Poisson: parallelepiped; one (E,nu) per element).  Some element failed the test: the plan
-    // drops to the general kernel for good and K is assembled again, overwriting every value of
-    // the first attempt.
-    p->fast_level = 0;
+  while (d_vals && p->used_fast && flags[1]) {
+    // The fast kernels verify their premise exactly (level 2: rectilinear mesh, one (E,nu) per
+    // element; Poisson level 1: parallelepiped elements).  The test failed somewhere: the plan drops
+    // a level for good (Poisson 2 -> 1 -> 0, elastic 2 -> 0) and K is assembled again, overwriting
+    // every value of the previous attempt.
+    p->fast_level = (p->kind == KIND_POISSON && p->fast_level == 2) ? 1 : 0;
     p->used_fast = false;
     HIPCHK(hipMemsetAsync(p->bad, 0, 3 * sizeof(unsigned long long), p->stream));
     t0 = std::chrono::steady_clock::now();
@@ -629,7 +638,7 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
     HIPCHK(hipMemcpyAsync(flags, p->bad, sizeof flags, hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     k_ms_redo = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (vals_host) {
+    if (vals_host && !(p->used_fast && flags[1])) {
       t0 = std::chrono::steady_clock::now();
       HIPCHK(hipMemcpyAsync(csr_values, d_vals, p->nnz * sizeof(double), hipMemcpyDeviceToHost, p->stream));
       HIPCHK(hipStreamSynchronize(p->stream));
@@ -712,7 +721,7 @@ int femasm_assemble_interface(femasm_plan *p, const femasm_material *mat, const 
   p->time_main = false;
   int rc = 0;
   unsigned long long flags[3] = {0, 0, 0};
-  for (int attempt = 0; attempt < 2; attempt++) {
+  for (int attempt = 0; attempt < 3; attempt++) {
     p->used_fast = false;
     HIPCHK(hipMemsetAsync(p->bad, 0, 3 * sizeof(unsigned long long), p->stream));
     switch (p->kind) {
@@ -726,7 +735,7 @@ int femasm_assemble_interface(femasm_plan *p, const femasm_material *mat, const 
     HIPCHK(hipMemcpyAsync(flags, p->bad, sizeof flags, hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     if (!(p->used_fast && flags[1])) break;
-    p->fast_level = 0;
+    p->fast_level = (p->kind == KIND_POISSON && p->fast_level == 2) ? 1 : 0;
   }
   if (flags[2]) return fail(FEMASM_ERR_HIP, "internal: %llu wave hand-shakes of the row-sweep kernel timed out", flags[2]);
   if (flags[0]) return fail(FEMASM_ERR_GEOMETRY, "%llu Gauss points with non-positive or NaN det(J)", flags[0]);

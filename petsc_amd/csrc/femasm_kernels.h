@@ -124,6 +124,7 @@ struct KArgs {
   int32_t bc;             // BC_* kind
   int32_t iface;          // 1: interface pass (elastic BC rows become zero rows)
   int32_t zc;             // row-sweep kernels: node layers (rows in 2-D) per workgroup
+  int32_t rect;           // row-sweep kernels: the mesh was verified rectilinear (k_check_rectilinear): geometry from 1-D lines
 };
 
 // isotropic coefficient triple scaled by w*detJ, in the reference's operation order
@@ -1132,6 +1133,24 @@ __global__ __launch_bounds__(256) void k_iface_apply(const Slab s, int bc, doubl
     const int64_t lr = (q + nnode * (layer - s.ks)) * s.dof + c;
     b[lr] = b[lr] + recvB[q * s.dof + c];
   }
+}
+
+// ---------------------------------------------------------------------------
+// Rectilinear-mesh test (3-D): x depends on i only, y on j only, z on k only -- bitwise, for every node of the
+// slab's coordinate layers.  Then every element is an axis-aligned box and its Jacobian follows from three
+// 1-D coordinate lines.  One flag increment per wave that sees a violation.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_check_rectilinear(const Slab s, const double *coords, int64_t nlayers,
+                                                           unsigned long long *flag) {
+  const int64_t M = s.dim[0], N = s.dim[1];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t j = blockIdx.y, kl = blockIdx.z;
+  bool bad = false;
+  if (i < M && kl < nlayers) {
+    const double *c = coords + 3 * (i + M * (j + N * kl));
+    bad = c[0] != coords[3 * i] || c[1] != coords[3 * (M * j) + 1] || c[2] != coords[3 * (M * N * kl) + 2];
+  }
+  if (__ballot(bad) != 0ULL && (threadIdx.x & 63) == 0) atomicAdd(flag, 1ULL);
 }
 
 // ---------------------------------------------------------------------------

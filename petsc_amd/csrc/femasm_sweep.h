@@ -612,6 +612,7 @@ __global__ __launch_bounds__(64 * (3 + RowSweep<KIND>::NRW), 2) void k_assemble_
   };
   __syncthreads();  // counters initialised
   auto load_layer = [&](int64_t gk, double (*cr)[3], int ln) {  // node layer gk of the halo'd tile -> registers
+    if (a.rect) return;
     gk = gk < s.cks ? s.cks : (gk > a.cke - 1 ? a.cke - 1 : gk);
 #pragma unroll
     for (int ps = 0; ps < CPASS; ps++) {
@@ -632,6 +633,7 @@ __global__ __launch_bounds__(64 * (3 + RowSweep<KIND>::NRW), 2) void k_assemble_
     }
   };
   auto commit_layer = [&](int slot, const double (*cr)[3], int ln) {
+    if (a.rect) return;
 #pragma unroll
     for (int ps = 0; ps < CPASS; ps++) {
       if (ps % NRW != rw) continue;
@@ -684,25 +686,38 @@ __global__ __launch_bounds__(64 * (3 + RowSweep<KIND>::NRW), 2) void k_assemble_
         for (int q = 0; q < NPA; q++) dst[q * NS] = make_double2(0.0, 0.0);
         return;
       }
-      double x[8][3];
-#pragma unroll
-      for (int n = 0; n < 8; n++) {
-        const double *xn = (HDK[n] ? xt : xb) + 3 * ((ex + HDI[n]) + NXX * (ey + HDJ[n]));
-#pragma unroll
-        for (int d = 0; d < 3; d++) x[n][d] = xn[d];
-      }
-      // edges: xi-direction 0->3, 1->2, 4->7, 5->6 ; eta 0->1, 3->2, 4->5, 7->6 ; zeta 0->4, 1->5, 2->6, 3->7
       bool affine = true;
       double J[3][3];
+      if (a.rect) {
+        // verified rectilinear mesh: the element is the box X[ex..ex+1] x Y[ey..ey+1] x Z[l..l+1]; the same
+        // differences of the same coordinates as below, so the records are bitwise those of the other branch
+        const int l = (int)(L - L0);
 #pragma unroll
-      for (int d = 0; d < 3; d++) {
-        const double e1 = x[3][d] - x[0][d], e2 = x[1][d] - x[0][d], e3 = x[4][d] - x[0][d];
-        affine = affine && (x[2][d] - x[1][d] == e1) && (x[7][d] - x[4][d] == e1) && (x[6][d] - x[5][d] == e1);
-        affine = affine && (x[2][d] - x[3][d] == e2) && (x[5][d] - x[4][d] == e2) && (x[6][d] - x[7][d] == e2);
-        affine = affine && (x[5][d] - x[1][d] == e3) && (x[6][d] - x[2][d] == e3) && (x[7][d] - x[3][d] == e3);
-        J[0][d] = 0.5 * e1;  // J_rc = d x_c / d xi_r
-        J[1][d] = 0.5 * e2;
-        J[2][d] = 0.5 * e3;
+        for (int r_ = 0; r_ < 3; r_++)
+#pragma unroll
+          for (int d = 0; d < 3; d++) J[r_][d] = 0.0;
+        J[0][0] = 0.5 * (sh_x[0][ex + 1] - sh_x[0][ex]);
+        J[1][1] = 0.5 * (sh_x[1][ey + 1] - sh_x[1][ey]);
+        J[2][2] = 0.5 * (sh_x[2][l + 1] - sh_x[2][l]);
+      } else {
+        double x[8][3];
+#pragma unroll
+        for (int n = 0; n < 8; n++) {
+          const double *xn = (HDK[n] ? xt : xb) + 3 * ((ex + HDI[n]) + NXX * (ey + HDJ[n]));
+#pragma unroll
+          for (int d = 0; d < 3; d++) x[n][d] = xn[d];
+        }
+        // edges: xi-direction 0->3, 1->2, 4->7, 5->6 ; eta 0->1, 3->2, 4->5, 7->6 ; zeta 0->4, 1->5, 2->6, 3->7
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          const double e1 = x[3][d] - x[0][d], e2 = x[1][d] - x[0][d], e3 = x[4][d] - x[0][d];
+          affine = affine && (x[2][d] - x[1][d] == e1) && (x[7][d] - x[4][d] == e1) && (x[6][d] - x[5][d] == e1);
+          affine = affine && (x[2][d] - x[3][d] == e2) && (x[5][d] - x[4][d] == e2) && (x[6][d] - x[7][d] == e2);
+          affine = affine && (x[5][d] - x[1][d] == e3) && (x[6][d] - x[2][d] == e3) && (x[7][d] - x[3][d] == e3);
+          J[0][d] = 0.5 * e1;  // J_rc = d x_c / d xi_r
+          J[1][d] = 0.5 * e2;
+          J[2][d] = 0.5 * e3;
+        }
       }
       if constexpr (HASMAT) {  // elastic: axis-aligned boxes only
         double E = a.E, nu = a.nu;
@@ -797,6 +812,23 @@ __global__ __launch_bounds__(64 * (3 + RowSweep<KIND>::NRW), 2) void k_assemble_
   };
 
   // prologue: node layers L0..L0+2, records of element layers L0 and L0+1; requests for steps 0 and 1
+  if (a.rect) {  // the three coordinate lines of this workgroup: X[i0-1 ..], Y[j0-1 ..], Z[L0 ..], clamped like the layers
+    if (lane < NXX) {
+      int64_t gi = i0 - 1 + lane;
+      gi = gi < 0 ? 0 : (gi > M - 1 ? M - 1 : gi);
+      sh_x[0][lane] = a.coords[3 * gi];
+    }
+    if (lane < R_::TY + 2) {
+      int64_t gj = j0 - 1 + lane;
+      gj = gj < 0 ? 0 : (gj > N - 1 ? N - 1 : gj);
+      sh_x[1][lane] = a.coords[3 * (M * gj) + 1];
+    }
+    for (int q = lane; q < nz + 3; q += 64) {
+      int64_t gk = L0 + q;
+      gk = gk < s.cks ? s.cks : (gk > a.cke - 1 ? a.cke - 1 : gk);
+      sh_x[2][q] = a.coords[3 * (M * N * (gk - s.cks)) + 2];
+    }
+  }
 #pragma unroll 1
   for (int q = 0; q < 3; q++) {
     load_layer(L0 + q, cr[0], lane);
