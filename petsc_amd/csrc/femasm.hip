@@ -206,6 +206,14 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
       const KArgs a = make_kargs<KIND>(p, mat, bc, out, b, s0, iface);
       const bool fast = (KIND == KIND_ELASTIC) ? (p->fast_level == 2) : (p->fast_level >= 1);
       const bool timed = p->time_main && !iface;
+      const bool rect = fast && p->fast_level == 2;
+      if (rect) {  // level 2: geometry from three coordinate lines, after an exact test that the mesh is rectilinear
+        const int64_t nlayers = p->cke - p->s.cks;
+        int64_t nb = N * nlayers;
+        if (nb > (int64_t)p->ncu * 16) nb = (int64_t)p->ncu * 16;
+        hipLaunchKernelGGL(k_check_rectilinear, dim3((unsigned)nb), dim3(256), 0, p->stream, p->s, p->coords, nlayers,
+                           p->bad + 1);
+      }
       if (timed) {
         HIPCHK(hipEventRecord(p->ev[4], p->stream));
         const bool aos3 = (KIND != KIND_POISSON) && mat && mat->layout == FEMASM_MAT_AOS;
@@ -225,12 +233,7 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
         if (zc > 128) zc = 128;
         KArgs az = a;
         az.zc = (int32_t)zc;
-        az.rect = (p->fast_level == 2) ? 1 : 0;
-        if (az.rect) {  // level 2: geometry from three coordinate lines, after an exact test that the mesh is rectilinear
-          const int64_t nlayers = p->cke - p->s.cks;
-          hipLaunchKernelGGL(k_check_rectilinear, dim3(nblk(M), (unsigned)N, (unsigned)nlayers), dim3(256), 0, p->stream,
-                             p->s, p->coords, nlayers, p->bad + 1);
-        }
+        az.rect = rect ? 1 : 0;
         dim3 grid((unsigned)((b.x1 - b.x0 + TX - 1) / TX), (unsigned)((b.y1 - b.y0 + TY - 1) / TY),
                   (unsigned)((z1 - z0 + zc - 1) / zc));
         hipLaunchKernelGGL(k_assemble_rowsweep<KIND>, grid, dim3(64 * (3 + RowSweep<KIND>::NRW)), 0, p->stream, p->s, az);

@@ -1142,13 +1142,22 @@ __global__ __launch_bounds__(256) void k_iface_apply(const Slab s, int bc, doubl
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_check_rectilinear(const Slab s, const double *coords, int64_t nlayers,
                                                            unsigned long long *flag) {
+  // the coordinate array as a flat stream of doubles: one x-row of nodes (3M doubles) per pass of the workgroup,
+  // 8 B per lane, coalesced; the j- and k-line references are uniform per row, the i-line is 3M hot doubles
   const int64_t M = s.dim[0], N = s.dim[1];
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t j = blockIdx.y, kl = blockIdx.z;
+  const int64_t nrows = N * nlayers;
+  const int n3 = (int)(3 * M);
   bool bad = false;
-  if (i < M && kl < nlayers) {
-    const double *c = coords + 3 * (i + M * (j + N * kl));
-    bad = c[0] != coords[3 * i] || c[1] != coords[3 * (M * j) + 1] || c[2] != coords[3 * (M * N * kl) + 2];
+  for (int64_t r = blockIdx.x; r < nrows; r += gridDim.x) {
+    const int64_t kl = r / N, j = r - kl * N;
+    const double *row = coords + 3 * M * r;
+    const double yref = coords[3 * (M * j) + 1], zref = coords[3 * (M * N * kl) + 2];
+    for (int t = threadIdx.x; t < n3; t += 256) {
+      const int c = t % 3;
+      const double v = row[t];
+      const double ref = c == 0 ? coords[t] : (c == 1 ? yref : zref);
+      bad |= v != ref;
+    }
   }
   if (__ballot(bad) != 0ULL && (threadIdx.x & 63) == 0) atomicAdd(flag, 1ULL);
 }
