@@ -269,6 +269,11 @@ def main():
             "k_ms": k_avg_ms,
             "rhs_ms": st.ms_kernel_rhs,
         }
+        # the whole K assembly of this rank (every stiffness kernel incl. Dirichlet rows and the pre-pass) against
+        # SURVEY 8(d)'s formula (femasm_stats.bytes_K = 8 nnz + 8 NSD nnodes + 16 NGP nel [E,nu per Gauss point])
+        k_gbs = st.bytes_K / (k_avg_ms * 1e-3) / 1e9
+        out["k_assembly"] = {"algorithmic_bytes": st.bytes_K, "ms": k_avg_ms, "achieved_GBps": k_gbs,
+                             "frac": k_gbs / HBM_PEAK_GBS}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(out), flush=True)

@@ -186,6 +186,26 @@ int femasm_fill_properties(femasm_plan *plan, double E, double nu, int32_t strid
  * sums (MPI_Allreduce, P3:510-513) and takes the square roots; h = 1/(M-1).  3-D kinds only. */
 int femasm_error_integrals(femasm_plan *plan, const double *u, double sums[2]);
 
+/* SURVEY 8(f) row N2, the step after the path: landing K in a (device-resident) PETSc Mat without the host.
+ * Either hand femasm_assemble_system the Mat's own value array (MatSeqAIJGetCSRAndMemType /
+ * MatSeqAIJGetArray: the pattern is DMCreateMatrix's), or use PETSc's COO interface: this entry writes the
+ * GLOBAL row and column index of every slot of csr_values, in that array's order, for
+ * MatSetPreallocationCOO(A, nnz, coo_i, coo_j) once and MatSetValuesCOO(A, csr_values, INSERT_VALUES) per
+ * assembly (call sites P3:681-685, S3:1394-1397).  index_bytes = sizeof(PetscInt) (4 or 8); HOST or DEVICE. */
+int femasm_coo_indices(femasm_plan *plan, int32_t index_bytes, void *coo_i, void *coo_j);
+
+/* SURVEY 8(f) row N4, second half: the rigid-body near-nullspace vectors the elasticity drivers hand to the
+ * preconditioner (MatNullSpaceCreateRigidBody on the DMDA coordinates, E2:682-685, S3:1374-1377): translations
+ * 1/sqrt(Nnodes) e_k, then the rotations (y,-x,0), (0,-z,y), (z,0,-x) (2-D: (-y,x)), each orthogonalised
+ * against the vectors before it and normalised (PETSc's published algorithm; PETSc is not in the reference
+ * tree: parity unpinned).  Two calls so that the only global reduction stays with the caller:
+ *   femasm_coord_moments: mom = sums over the OWNED nodes of [1, x, y, z, xx, yy, zz, xy, yz, zx]; the caller
+ *     adds the ranks' arrays (MPI_Allreduce / RCCL all-reduce of 10 doubles; nothing to do on one GPU);
+ *   femasm_rigid_body_modes: modes[m*nrows + r], m < 6 (3 in 2-D), owned rows r, from the GLOBAL moments;
+ *     HOST or DEVICE. */
+int femasm_coord_moments(femasm_plan *plan, double mom[10]);
+int femasm_rigid_body_modes(femasm_plan *plan, const double mom[10], double *modes);
+
 /* Block until everything queued on the plan's stream has finished. */
 int femasm_plan_sync(femasm_plan *plan);
 

@@ -995,4 +995,116 @@ int femasm_compress_bc_rows(femasm_plan *p, const femasm_bc *bcs, const double *
   return rc;
 }
 
+int femasm_coo_indices(femasm_plan *p, int32_t index_bytes, void *coo_i, void *coo_j) {
+  if (!p || !coo_i || !coo_j) return fail(FEMASM_ERR_ARG, "null argument");
+  if (index_bytes != 4 && index_bytes != 8) return fail(FEMASM_ERR_ARG, "index_bytes must be 4 or 8 (PetscInt)");
+  HIPCHK(hipSetDevice(p->device));
+  const bool dev = is_device_ptr(coo_i);
+  if (dev != is_device_ptr(coo_j)) return fail(FEMASM_ERR_ARG, "coo_i and coo_j must be both host or both device");
+  const Slab &s = p->s;
+  const int64_t plane = (s.nsd == 3) ? s.dim[0] * s.dim[1] : s.dim[0];
+  const int64_t row0 = plane * s.ks * s.dof;
+  const int64_t ntot = plane * (s.nsd == 3 ? s.dim[2] : s.dim[1]) * s.dof;
+  if (index_bytes == 4 && ntot > INT32_MAX) return fail(FEMASM_ERR_ARG, "global row ids need 64-bit indices");
+  const size_t bytes = (size_t)p->nnz * index_bytes;
+  void *di = coo_i, *dj = coo_j;
+  if (!dev) {
+    HIPCHK(hipMalloc(&di, bytes));
+    if (hipMalloc(&dj, bytes) != hipSuccess) { (void)hipFree(di); return fail(FEMASM_ERR_NOMEM, "coo staging"); }
+  }
+  if (index_bytes == 4)
+    hipLaunchKernelGGL(k_coo_indices<int32_t>, dim3(nblk(p->nrows, 4)), dim3(256), 0, p->stream, p->nrows, row0,
+                       p->rowptr, p->colidx, (int32_t *)di, (int32_t *)dj);
+  else
+    hipLaunchKernelGGL(k_coo_indices<int64_t>, dim3(nblk(p->nrows, 4)), dim3(256), 0, p->stream, p->nrows, row0,
+                       p->rowptr, p->colidx, (int64_t *)di, (int64_t *)dj);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && !dev) e = hipMemcpyAsync(coo_i, di, bytes, hipMemcpyDeviceToHost, p->stream);
+  if (e == hipSuccess && !dev) e = hipMemcpyAsync(coo_j, dj, bytes, hipMemcpyDeviceToHost, p->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+  if (!dev) { (void)hipFree(di); (void)hipFree(dj); }
+  if (e != hipSuccess) return fail(FEMASM_ERR_HIP, "femasm_coo_indices: %s", hipGetErrorString(e));
+  return FEMASM_OK;
+}
+
+int femasm_coord_moments(femasm_plan *p, double mom[10]) {
+  if (!p || !mom) return fail(FEMASM_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(p->device));
+  const Slab &s = p->s;
+  const int64_t nown = p->nrows / s.dof;
+  for (int q = 0; q < 10; q++) mom[q] = 0.0;
+  if (nown <= 0) return FEMASM_OK;
+  int64_t nb = (nown + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  double *partial = nullptr;
+  HIPCHK(hipMalloc(&partial, (10 * nb + 10) * sizeof(double)));
+  hipLaunchKernelGGL(k_coord_moments, dim3((unsigned)nb), dim3(256), 0, p->stream, s, p->coords, nown, partial);
+  hipLaunchKernelGGL(k_sum_rows10, dim3(1), dim3(64), 0, p->stream, partial, nb, partial + 10 * nb);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(mom, partial + 10 * nb, 10 * sizeof(double), hipMemcpyDeviceToHost, p->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+  (void)hipFree(partial);
+  if (e != hipSuccess) return fail(FEMASM_ERR_HIP, "femasm_coord_moments: %s", hipGetErrorString(e));
+  return FEMASM_OK;
+}
+
+int femasm_rigid_body_modes(femasm_plan *p, const double mom[10], double *modes) {
+  if (!p || !mom || !modes) return fail(FEMASM_ERR_ARG, "null argument");
+  if (p->kind == KIND_POISSON) return fail(FEMASM_ERR_ARG, "rigid-body modes belong to the elasticity kinds");
+  if (!(mom[0] >= 1.0)) return fail(FEMASM_ERR_ARG, "mom[0] (global node count) must be >= 1");
+  HIPCHK(hipSetDevice(p->device));
+  const Slab &s = p->s;
+  const int nsd = s.nsd, nm = (nsd == 3) ? 6 : 3;
+  const double sN = 1.0 / sqrt(mom[0]);
+  const double Sx = mom[1], Sy = mom[2], Sz = mom[3], Sxx = mom[4], Syy = mom[5], Szz = mom[6], Sxy = mom[7],
+               Syz = mom[8], Szx = mom[9];
+  // Gram matrix of the raw vectors
+  double G[6][6] = {};
+  for (int k = 0; k < nsd; k++) G[k][k] = mom[0] * sN * sN;
+  if (nsd == 3) {
+    G[0][3] = sN * Sy;  G[1][3] = -sN * Sx;
+    G[1][4] = -sN * Sz; G[2][4] = sN * Sy;
+    G[0][5] = sN * Sz;  G[2][5] = -sN * Sx;
+    G[3][3] = Syy + Sxx; G[4][4] = Szz + Syy; G[5][5] = Szz + Sxx;
+    G[3][4] = Szx; G[3][5] = Syz; G[4][5] = -Sxy;
+  } else {
+    G[0][2] = -sN * Sy; G[1][2] = sN * Sx; G[2][2] = Syy + Sxx;
+  }
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < i; j++) G[i][j] = G[j][i];
+  // classical Gram-Schmidt of vector i against the finished 0..i-1, then normalise -- in coefficient space
+  RigidArgs a = {};
+  a.sN = sN;
+  a.nmodes = nm;
+  for (int k = 0; k < nsd; k++) a.C[k][k] = 1.0;
+  for (int i = nsd; i < nm; i++) {
+    double u[6] = {};
+    u[i] = 1.0;
+    for (int j = 0; j < i; j++) {
+      double dot = 0.0;
+      for (int k = 0; k < nm; k++) dot += a.C[j][k] * G[k][i];
+      for (int k = 0; k < nm; k++) u[k] -= dot * a.C[j][k];
+    }
+    double n2 = 0.0;
+    for (int k = 0; k < nm; k++)
+      for (int l = 0; l < nm; l++) n2 += u[k] * G[k][l] * u[l];
+    if (!(n2 > 0.0)) return fail(FEMASM_ERR_GEOMETRY, "rigid-body mode %d is degenerate (all nodes on a line?)", i);
+    const double inv = 1.0 / sqrt(n2);
+    for (int k = 0; k < nm; k++) a.C[i][k] = u[k] * inv;
+  }
+  const int64_t nown = p->nrows / s.dof;
+  if (nown <= 0) return FEMASM_OK;
+  const bool dev = is_device_ptr(modes);
+  const size_t bytes = (size_t)nm * p->nrows * sizeof(double);
+  double *d = modes;
+  if (!dev) HIPCHK(hipMalloc(&d, bytes));
+  hipLaunchKernelGGL(k_rigid_modes, dim3(nblk(nown)), dim3(256), 0, p->stream, s, p->coords, nown, a, d);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && !dev) e = hipMemcpyAsync(modes, d, bytes, hipMemcpyDeviceToHost, p->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+  if (!dev) (void)hipFree(d);
+  if (e != hipSuccess) return fail(FEMASM_ERR_HIP, "femasm_rigid_body_modes: %s", hipGetErrorString(e));
+  return FEMASM_OK;
+}
+
 }  // extern "C"

@@ -1444,4 +1444,94 @@ __global__ __launch_bounds__(256) void k_bc_compress(const Slab s, int bc, int64
   }
 }
 
+// ---------------------------------------------------------------------------
+// N2: coordinate (COO) form of the pattern in the order of the CSR value array, for MatSetPreallocationCOO /
+// MatSetValuesCOO: one wave per row.  I = PetscInt (32 or 64 bit).
+// ---------------------------------------------------------------------------
+template <typename I>
+__global__ __launch_bounds__(256) void k_coo_indices(int64_t nrows, int64_t row0, const int64_t *rowptr,
+                                                     const int32_t *colidx, I *coo_i, I *coo_j) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= nrows) return;
+  const int64_t e = rowptr[r + 1];
+  for (int64_t t = rowptr[r] + (threadIdx.x & 63); t < e; t += 64) {
+    coo_i[t] = (I)(row0 + r);
+    coo_j[t] = (I)colidx[t];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// N4 (second half): rigid-body near-nullspace vectors, the input of MatNullSpaceCreateRigidBody (E2:682-685,
+// S3:1374-1377).  Pass 1: first and second moments of the owned nodes' coordinates, one row of 10 partial sums
+// per workgroup (fixed order: deterministic).  Pass 2: the modes as a linear combination C of the raw vectors
+// (translations sN e_k; rotations (y,-x,0), (0,-z,y), (z,0,-x); 2-D: (-y,x)).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_coord_moments(const Slab s, const double *coords, int64_t nown,
+                                                       double *partial /*[gridDim.x][10]*/) {
+  __shared__ double red[10][256];
+  const int64_t plane = (s.nsd == 3) ? s.dim[0] * s.dim[1] : s.dim[0];
+  const double *c0 = coords + (s.ks - s.cks) * plane * s.nsd;
+  double m[10];
+#pragma unroll
+  for (int q = 0; q < 10; q++) m[q] = 0.0;
+  for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < nown; n += (int64_t)gridDim.x * 256) {
+    const double x = c0[s.nsd * n], y = c0[s.nsd * n + 1], z = (s.nsd == 3) ? c0[3 * n + 2] : 0.0;
+    m[0] += 1.0; m[1] += x; m[2] += y; m[3] += z;
+    m[4] += x * x; m[5] += y * y; m[6] += z * z;
+    m[7] += x * y; m[8] += y * z; m[9] += z * x;
+  }
+#pragma unroll
+  for (int q = 0; q < 10; q++) red[q][threadIdx.x] = m[q];
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st)
+#pragma unroll
+      for (int q = 0; q < 10; q++) red[q][threadIdx.x] += red[q][threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x < 10) partial[10 * (int64_t)blockIdx.x + threadIdx.x] = red[threadIdx.x][0];
+}
+__global__ __launch_bounds__(64) void k_sum_rows10(const double *partial, int64_t n, double *out) {
+  if (threadIdx.x >= 10) return;
+  double a = 0.0;
+  for (int64_t q = 0; q < n; q++) a += partial[10 * q + threadIdx.x];
+  out[threadIdx.x] = a;
+}
+struct RigidArgs {
+  double C[6][6];  // mode m = sum_k C[m][k] raw_k
+  double sN;
+  int32_t nmodes;
+};
+__global__ __launch_bounds__(256) void k_rigid_modes(const Slab s, const double *coords, int64_t nown,
+                                                     const RigidArgs a, double *modes /*[nmodes][nown*nsd]*/) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= nown) return;
+  const int nsd = s.nsd;
+  const int64_t plane = (nsd == 3) ? s.dim[0] * s.dim[1] : s.dim[0];
+  const double *c0 = coords + (s.ks - s.cks) * plane * nsd;
+  const double x = c0[nsd * n], y = c0[nsd * n + 1], z = (nsd == 3) ? c0[3 * n + 2] : 0.0;
+  double raw[6][3];
+#pragma unroll
+  for (int k = 0; k < 6; k++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) raw[k][c] = 0.0;
+  if (nsd == 3) {
+    raw[0][0] = a.sN; raw[1][1] = a.sN; raw[2][2] = a.sN;
+    raw[3][0] = y;  raw[3][1] = -x;
+    raw[4][1] = -z; raw[4][2] = y;
+    raw[5][0] = z;  raw[5][2] = -x;
+  } else {
+    raw[0][0] = a.sN; raw[1][1] = a.sN;
+    raw[2][0] = -y; raw[2][1] = x;
+  }
+  const int64_t nr = nown * nsd;
+  for (int m = 0; m < a.nmodes; m++)
+    for (int c = 0; c < nsd; c++) {
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) v += a.C[m][k] * raw[k][c];
+      modes[m * nr + nsd * n + c] = v;
+    }
+}
+
 }  // namespace femasm

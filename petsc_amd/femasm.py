@@ -31,6 +31,7 @@ EXPORTS = [
     "femasm_pattern_copy", "femasm_scatter_map", "femasm_assemble_system", "femasm_interface_buffers",
     "femasm_interface_set_buffers", "femasm_interface_apply", "femasm_compress_bc_rows", "femasm_plan_sync", "femasm_last_error",
     "femasm_version", "femasm_plan_set_fast_path", "femasm_plan_get_fast_path", "femasm_assemble_interface", "femasm_error_integrals", "femasm_fill_properties", "femasm_apply_operator",
+    "femasm_coo_indices", "femasm_coord_moments", "femasm_rigid_body_modes",
 ]
 
 
@@ -227,6 +228,22 @@ class Plan:
         out = (C.c_double * 2)()
         _check(load().femasm_error_integrals(self._h, _ptr(u), out))
         return out[0], out[1]
+
+    def coo_indices(self, coo_i, coo_j):
+        """Global (row, column) of every CSR value slot, into two int32 or int64 arrays/tensors of nnz entries."""
+        nbytes = coo_i.dtype.itemsize if isinstance(coo_i, np.ndarray) else coo_i.element_size()
+        _check(load().femasm_coo_indices(self._h, C.c_int32(nbytes), _ptr(coo_i), _ptr(coo_j)))
+
+    def coord_moments(self):
+        """[count, Sx, Sy, Sz, Sxx, Syy, Szz, Sxy, Syz, Szx] over the owned nodes (add over ranks)."""
+        out = (C.c_double * 10)()
+        _check(load().femasm_coord_moments(self._h, out))
+        return np.array(out[:], dtype=np.float64)
+
+    def rigid_body_modes(self, moments, out):
+        """Orthonormal rigid-body modes (6 x nrows, 3 x nrows in 2-D) from the GLOBAL moments."""
+        mom = (C.c_double * 10)(*[float(v) for v in moments])
+        _check(load().femasm_rigid_body_modes(self._h, mom, _ptr(out)))
 
     def compress_bc_rows(self, values, bc):
         """PETSc's truncated MatZeroRows storage; host numpy in, host numpy out."""

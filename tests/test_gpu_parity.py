@@ -563,3 +563,124 @@ def test_operator_apply_over_slabs_with_the_interface_exchange(env):
     assert rel(y, K @ x) <= 1e-12
     for p in plans:
         p.close()
+
+
+def _fixture_names():
+    import os
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "systems.npz"))
+    return sorted({k.split("/")[0] for k in f.files})
+
+
+@pytest.mark.parametrize("name", _fixture_names())
+def test_committed_system_fixtures(env, name):
+    """The HIP path against tests/golden/systems.npz (no oracle call: the expected K and b are data)."""
+    import os
+    torch, F, dev = env["torch"], env["F"], env["dev"]
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "systems.npz"))
+    kind, M, N, P, stride = (int(v) for v in f[name + "/meta"])
+    problem = [F.POISSON3D_Q1, F.PLANE_STRAIN2D_Q1, F.ELASTIC3D_Q1][kind]
+    bc = [F.BC_POISSON_INLOOP, F.BC_E2_COMPRESSION, F.BC_S3_ALLFACES_EXACT][kind]
+    case = dict(problem=problem, dims=(M, N, P), coords=f[name + "/coords"],
+                props=f[name + "/props"] if stride else None, stride=stride, bc=bc)
+    plan, vals, b = gpu_assemble(env, case)
+    assert rel(vals, f[name + "/K"]) <= TOL and rel(b, f[name + "/b"]) <= TOL
+    plan.close()
+
+
+# --------------------------------------------------------------------------
+# N2: COO landing; N4 second half: rigid-body near-nullspace
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("kind,dims,dtype", [("p3", (5, 4, 6), np.int32), ("s3", (4, 5, 7), np.int64), ("e2", (9, 6), np.int32)])
+def test_coo_indices_address_the_csr_value_slots(env, kind, dims, dtype):
+    """MatSetValuesCOO(A, vals) with these indices must build the same matrix as the CSR arrays: bit-exact
+    integer work, single GPU and per slab (global row ids)."""
+    torch, F, dev, slab = env["torch"], env["F"], env["dev"], env["slab"]
+    case = make_case(env, kind, dims)
+    M, N, P = case["dims"]
+    L = P if kind != "e2" else N
+    dof = {"p3": 1, "e2": 2, "s3": 3}[kind]
+    plane = M * N if kind != "e2" else M
+    expect_i = np.repeat(np.arange(len(case["rp"]) - 1), np.diff(case["rp"]))
+    for ks, ke in [(0, L)] + list(slab.slab_ranges(L, 2)):
+        cks, cke = max(ks - 1, 0), min(ke + 1, L)
+        cl = case["coords"].reshape(L, -1)[cks:cke].reshape(-1)
+        plan = F.Plan(case["problem"], M, N, P, coords=torch.from_numpy(cl).to(dev), ks=ks, ke=ke, cks=cks, cke=cke)
+        ci_ = torch.empty(plan.nnz, dtype=torch.int32 if dtype == np.int32 else torch.int64, device=dev)
+        cj_ = torch.empty_like(ci_)
+        plan.coo_indices(ci_, cj_)
+        r0, r1 = plane * ks * dof, plane * ke * dof
+        a, b = case["rp"][r0], case["rp"][r1]
+        assert np.array_equal(ci_.cpu().numpy(), expect_i[a:b]) and np.array_equal(cj_.cpu().numpy(), case["ci"][a:b])
+        hi, hj = np.empty(plan.nnz, dtype=dtype), np.empty(plan.nnz, dtype=dtype)  # host outputs
+        plan.coo_indices(hi, hj)
+        assert np.array_equal(hi, expect_i[a:b]) and np.array_equal(hj, case["ci"][a:b])
+        plan.close()
+
+
+def _petsc_rigid_body(coords, nsd):
+    """MatNullSpaceCreateRigidBody as PETSc documents it (src/mat/interface/matnull.c; PETSc is not part of the
+    reference tree -- parity unpinned): raw vectors, then classical Gram-Schmidt + normalise of the rotations."""
+    x = coords.reshape(-1, nsd)
+    n = len(x)
+    sN = 1.0 / np.sqrt(n)
+    nm = 6 if nsd == 3 else 3
+    v = np.zeros((nm, n, nsd))
+    for k in range(nsd):
+        v[k, :, k] = sN
+    if nsd == 3:
+        v[3, :, 0], v[3, :, 1] = x[:, 1], -x[:, 0]
+        v[4, :, 1], v[4, :, 2] = -x[:, 2], x[:, 1]
+        v[5, :, 0], v[5, :, 2] = x[:, 2], -x[:, 0]
+    else:
+        v[2, :, 0], v[2, :, 1] = -x[:, 1], x[:, 0]
+    v = v.reshape(nm, -1)
+    for i in range(nsd, nm):
+        dots = v[:i] @ v[i]
+        v[i] = v[i] - dots @ v[:i]
+        v[i] /= np.linalg.norm(v[i])
+    return v
+
+
+@pytest.mark.parametrize("kind,dims", [("s3", (5, 4, 6)), ("e2", (7, 9))])
+def test_rigid_body_modes(env, kind, dims):
+    """Orthonormal, equal to PETSc's construction, in the kernel of the unconstrained K (any mesh), and the same
+    whether built on one GPU or slab by slab from the summed moments."""
+    torch, F, dev, slab, O = env["torch"], env["F"], env["dev"], env["slab"], env["O"]
+    case = make_case(env, kind, dims, perturb=True)
+    M, N, P = case["dims"]
+    nsd = 3 if kind == "s3" else 2
+    L = P if nsd == 3 else N
+    nm = 6 if nsd == 3 else 3
+    ref = _petsc_rigid_body(case["coords"], nsd)
+    plan = F.Plan(case["problem"], M, N, P, coords=torch.from_numpy(case["coords"]).to(dev))
+    mom = plan.coord_moments()
+    x = case["coords"].reshape(-1, nsd)
+    assert mom[0] == len(x) and abs(mom[1] - x[:, 0].sum()) < 1e-12 * len(x)
+    modes = torch.empty(nm * plan.nrows, dtype=torch.float64, device=dev)
+    plan.rigid_body_modes(mom, modes)
+    Q = modes.cpu().numpy().reshape(nm, -1)
+    assert np.abs(Q @ Q.T - np.eye(nm)).max() < 1e-12
+    assert np.abs(Q - ref).max() < 1e-12
+    # K (no Dirichlet rows) annihilates them
+    vals = torch.empty(plan.nnz, dtype=torch.float64, device=dev)
+    mat = torch.from_numpy(case["props"]).to(dev)
+    plan.assemble_system(vals, None, material=mat, stride=case["stride"], bc=F.BC_NONE)
+    import scipy.sparse as sp
+    K = sp.csr_matrix((vals.cpu().numpy(), case["ci"].astype(np.int64), case["rp"]), shape=(plan.nrows, plan.nrows))
+    assert np.abs(K @ Q.T).max() < 1e-10 * np.abs(vals.cpu().numpy()).max()
+    plan.close()
+    # slab by slab, host output
+    parts, moms, plans = [], [], []
+    for ks, ke in slab.slab_ranges(L, 3):
+        cks, cke = max(ks - 1, 0), min(ke + 1, L)
+        cl = case["coords"].reshape(L, -1)[cks:cke].reshape(-1)
+        pl = F.Plan(case["problem"], M, N, P, coords=torch.from_numpy(cl).to(dev), ks=ks, ke=ke, cks=cks, cke=cke)
+        plans.append(pl)
+        moms.append(pl.coord_moments())
+    tot = np.sum(moms, axis=0)
+    for pl in plans:
+        out = np.empty(nm * pl.nrows)
+        pl.rigid_body_modes(tot, out)
+        parts.append(out.reshape(nm, -1))
+        pl.close()
+    assert np.abs(np.concatenate(parts, axis=1) - ref).max() < 1e-12

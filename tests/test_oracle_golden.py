@@ -190,3 +190,19 @@ def test_slab_element_ranges_sum_to_the_global_assembly(O):
         Ks += k1
         bs += b1
     assert np.abs(Ks - K).max() < 1e-15 and np.abs(bs - b).max() < 1e-15
+
+
+def test_oracle_reproduces_committed_system_fixtures(O):
+    """tests/golden/systems.npz (small full systems incl. distorted meshes, per-Gauss-point material, natural-BC
+    term, R3 stride) was written by this oracle; it must keep reproducing it to the last bit."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_system_fixtures",
+                                                  os.path.join(HERE, "golden", "make_system_fixtures.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    fix = np.load(os.path.join(HERE, "golden", "systems.npz"))
+    cases = gen.cases()
+    assert len(cases) == 11
+    for name, d in cases.items():
+        for k in ("coords", "props", "K", "b"):
+            assert np.array_equal(fix[name + "/" + k], d[k]), (name, k)
