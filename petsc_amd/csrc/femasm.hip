@@ -73,6 +73,7 @@ struct femasm_plan {
 
   // RHS scratch: per-element Fe (Ge)
   double *elemF = nullptr;
+  int64_t nelp = 0;                    // nel rounded up to whole blocks of 16 elements
   // interface buffers (K rows of one node layer in CSR layout, then the b slice)
   double *send = nullptr, *recv = nullptr;
   int64_t send_count = 0, recv_count = 0, send_nnz = 0, recv_nnz = 0;
@@ -85,6 +86,7 @@ struct femasm_plan {
   bool own_stream = false;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int ncu = 256;                       // compute units of the device
+  bool rect_checked = false;           // k_check_rectilinear ran on the stream in this call (its verdict is bad[3])
   bool iface_done = false;             // femasm_assemble_interface already filled the send buffer for the next call
   bool time_main = false;              // record ev[4], ev[5] around the dominant K kernel of the main pass
   double bytes_main = 0.0;             // its algorithmic bytes
@@ -206,14 +208,7 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
       const KArgs a = make_kargs<KIND>(p, mat, bc, out, b, s0, iface);
       const bool fast = (KIND == KIND_ELASTIC) ? (p->fast_level == 2) : (p->fast_level >= 1);
       const bool timed = p->time_main && !iface;
-      const bool rect = fast && p->fast_level == 2;
-      if (rect) {  // level 2: geometry from three coordinate lines, after an exact test that the mesh is rectilinear
-        const int64_t nlayers = p->cke - p->s.cks;
-        int64_t nb = N * nlayers;
-        if (nb > (int64_t)p->ncu * 16) nb = (int64_t)p->ncu * 16;
-        hipLaunchKernelGGL(k_check_rectilinear, dim3((unsigned)nb), dim3(256), 0, p->stream, p->s, p->coords, nlayers,
-                           p->bad + 1);
-      }
+      const bool rect = fast && p->fast_level == 2;  // level 2: geometry from three coordinate lines (launch_rect_check ran)
       if (timed) {
         HIPCHK(hipEventRecord(p->ev[4], p->stream));
         const bool aos3 = (KIND != KIND_POISSON) && mat && mat->layout == FEMASM_MAT_AOS;
@@ -262,6 +257,21 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
   }
 }
 
+// Level 2, 3-D: exact test that the slab's mesh is rectilinear, once per call before the stiffness and RHS kernels
+// that rely on it (flags bad[1] and bad[3]).
+int launch_rect_check(femasm_plan *p) {
+  p->rect_checked = false;
+  if (p->s.nsd != 3 || p->fast_level != 2) return 0;
+  const int64_t nlayers = p->cke - p->s.cks;
+  int64_t nb = p->s.dim[1] * nlayers;
+  if (nb > (int64_t)p->ncu * 16) nb = (int64_t)p->ncu * 16;
+  hipLaunchKernelGGL(k_check_rectilinear, dim3((unsigned)nb), dim3(256), 0, p->stream, p->s, p->coords, nlayers,
+                     p->bad + 1);
+  HIPCHK(hipGetLastError());
+  p->rect_checked = true;
+  return 0;
+}
+
 template <int KIND>
 int launch_rhs(femasm_plan *p, const femasm_material *mat, int bc, double *out, int64_t s0, int64_t s1, int iface,
                bool do_elem, const Slab *slab = nullptr, int64_t nel = -1) {
@@ -278,26 +288,33 @@ int launch_rhs(femasm_plan *p, const femasm_material *mat, int bc, double *out, 
   a.s0 = s0;
   a.s1 = s1;
   a.nel = nel;
-  a.nelp = (p->nel + 15) & ~(int64_t)15;
   a.mat_layout = mat ? mat->layout : FEMASM_MAT_UNIFORM;
   a.mat_stride = mat ? mat->stride : 0;
   a.bc = bc;
   a.iface = iface;
   a.bad = p->bad;
+  a.rect = p->rect_checked ? 1 : 0;
   if (do_elem && nel > 0) {
-    if (KIND == KIND_ELASTIC) {
-      // persistent workgroups: exactly one resident set, so that every one walks the same number of groups
-      static int wg_per_cu = 0, ncu = 0;
-      if (!wg_per_cu) {
+    // the cooperative streaming kernel reads the AoS records as 16-byte runs; anything else (uniform material:
+    // no loads, or an odd stride / odd base) takes the thread-per-element kernel
+    const bool coop = KIND == KIND_ELASTIC && a.gp && (a.mat_stride & 1) == 0 && ((uintptr_t)a.gp & 15) == 0 &&
+                      nel < ((int64_t)1 << 31);
+    if (coop) {
+      // persistent one-wave workgroups: exactly one resident set, so that every one walks the same number of groups
+      static int wg_per_cu[2] = {0, 0}, ncu = 0;
+      if (!wg_per_cu[0]) {
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, p->device));
         ncu = prop.multiProcessorCount;
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, k_rhs_elem_elastic_coop, 256, 0));
-        if (wg_per_cu < 1) wg_per_cu = 1;
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu[1], k_rhs_elem_elastic_oct<true>, 64, 0));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu[0], k_rhs_elem_elastic_oct<false>, 64, 0));
+        if (wg_per_cu[0] < 1) wg_per_cu[0] = 1;
+        if (wg_per_cu[1] < 1) wg_per_cu[1] = 1;
       }
-      const int64_t ngroups = (nel + 15) / 16 / 4 + 1, resident = (int64_t)ncu * wg_per_cu;  // 4 groups per workgroup pass
-      hipLaunchKernelGGL(k_rhs_elem_elastic_coop, dim3((unsigned)(ngroups < resident ? ngroups : resident)), dim3(256),
-                         0, p->stream, sl, a);
+      const int64_t ngroups = (nel + 15) / 16;
+      auto grid = [&](int v) { const int64_t r = (int64_t)ncu * wg_per_cu[v]; return dim3((unsigned)(ngroups < r ? ngroups : r)); };
+      if (a.rect) hipLaunchKernelGGL(k_rhs_elem_elastic_oct<true>, grid(1), dim3(64), 0, p->stream, sl, a);
+      hipLaunchKernelGGL(k_rhs_elem_elastic_oct<false>, grid(0), dim3(64), 0, p->stream, sl, a);
     }
     else
       hipLaunchKernelGGL(k_rhs_elem<KIND>, dim3(nblk(nel)), dim3(256), 0, p->stream, sl, a);
@@ -406,7 +423,9 @@ int femasm_plan_create(const femasm_mesh *mesh, const femasm_quad *quad, int dev
   }
   PCHK(hipMalloc(&p->bad, 32 * sizeof(unsigned long long)));  // [0] bad detJ, [1] fast-path premise failures, [2] hand-shake timeouts, rest: profiling builds
   PCHK(hipMemsetAsync(p->bad, 0, 32 * sizeof(unsigned long long), p->stream));
-  PCHK(hipMalloc(&p->elemF, (size_t)(((p->nel > 0 ? p->nel : 1) + 15) & ~(int64_t)15) * nen * dof * sizeof(double)));
+  // element vectors: blocks of 16 elements x nen*dof lines (ef_idx in femasm_kernels.h)
+  p->nelp = ((p->nel > 0 ? p->nel : 1) + 15) & ~(int64_t)15;
+  PCHK(hipMalloc(&p->elemF, (size_t)p->nelp * nen * dof * sizeof(double)));
 
   // interface buffers: rows of node layer ks-1 (owed to the rank below) and of ke-1 (owed to us)
   if (s.ks > 0) {
@@ -567,9 +586,10 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
   }
   ms_staging += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
-  HIPCHK(hipMemsetAsync(p->bad, 0, 3 * sizeof(unsigned long long), p->stream));
+  HIPCHK(hipMemsetAsync(p->bad, 0, 4 * sizeof(unsigned long long), p->stream));
 
-  int rc = 0;
+  int rc = launch_rect_check(p);
+  if (rc) return rc;
   // ---- K ----
   auto run_K = [&]() -> int {
     int r = 0;
@@ -635,6 +655,8 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
     p->fast_level = (p->kind == KIND_POISSON && p->fast_level == 2) ? 1 : 0;
     p->used_fast = false;
     HIPCHK(hipMemsetAsync(p->bad, 0, 3 * sizeof(unsigned long long), p->stream));
+    rc = launch_rect_check(p);  // (only if the plan is still at level 2, which it is not)
+    if (rc) return rc;
     t0 = std::chrono::steady_clock::now();
     rc = run_K();
     if (rc) return rc;
@@ -726,7 +748,9 @@ int femasm_assemble_interface(femasm_plan *p, const femasm_material *mat, const 
   unsigned long long flags[3] = {0, 0, 0};
   for (int attempt = 0; attempt < 3; attempt++) {
     p->used_fast = false;
-    HIPCHK(hipMemsetAsync(p->bad, 0, 3 * sizeof(unsigned long long), p->stream));
+    HIPCHK(hipMemsetAsync(p->bad, 0, 4 * sizeof(unsigned long long), p->stream));
+    rc = launch_rect_check(p);
+    if (rc) return rc;
     switch (p->kind) {
       case KIND_POISSON: rc = launch_K<KIND_POISSON>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1); break;
       case KIND_PLANE:   rc = launch_K<KIND_PLANE>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1); break;
@@ -788,7 +812,6 @@ int femasm_apply_operator(femasm_plan *p, const femasm_material *mat, const fema
   a.coords = p->coords;
   a.gp = (mloc.layout == FEMASM_MAT_AOS) ? mloc.gp : nullptr;
   a.elemF = p->elemF;
-  a.nelp = (p->nel + 15) & ~(int64_t)15;
   a.cke = p->cke;
   a.nel = p->nel;
   a.mat_layout = mloc.layout;

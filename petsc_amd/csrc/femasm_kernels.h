@@ -573,11 +573,16 @@ __global__ __launch_bounds__(256, 2) void k_assemble_rows(const Slab s, const KA
 #define PH_FLUSH(base)
 #endif
 
+// Element-vector array (pass 1 -> pass 2 of the RHS and of the operator apply): blocks of 16 consecutive
+// elements, NOUT = nen*dof lines of 16 doubles per block, so a block is NOUT*128 contiguous bytes.  (Component-major
+// rows over the whole mesh made every wave write NOUT single lines megabytes apart: 0.26 ms of 1.13 ms at 128^3.)
+template <int NOUT>
+__device__ inline int64_t ef_idx(int64_t e, int t) { return (e >> 4) * (NOUT * 16) + t * 16 + (e & 15); }
+
 struct RArgs {
   const double *coords;
   const double *gp;
-  double *elemF;          // element vectors, component-major: F[t][e], t = local node * dof + c, rows of nelp
-  int64_t nelp;           // nel rounded up to a multiple of 16 (rows start on 128-byte lines)
+  double *elemF;          // element vectors, blocks of 16 elements x (nen*dof) lines (ef_idx)
   double *out;            // b of the processed rows
   const double *recv;     // interface_apply
   int64_t cke;
@@ -587,6 +592,7 @@ struct RArgs {
   int32_t bc, iface;
   unsigned long long *bad;  // plan flags / profiling counters
   const double *x;          // N4 operator apply: input vector on the node layers of coords (else null)
+  int32_t rect;             // the rectilinearity pre-pass ran in this call: bad[3] == 0 <=> every element is a box
 };
 
 template <int KIND>
@@ -717,201 +723,218 @@ __global__ __launch_bounds__(256) void k_rhs_elem(const Slab s, const RArgs a) {
   constexpr int NOUT = T::NEN * T::DOF;
 #pragma unroll
   for (int q = 0; q < NOUT; q++) {
-    if constexpr (KIND == KIND_ELASTIC) a.elemF[q * a.nelp + e] = F[q] + F[NOUT + q];
-    else a.elemF[q * a.nelp + e] = F[q];
+    if constexpr (KIND == KIND_ELASTIC) a.elemF[ef_idx<NOUT>(e, q)] = F[q] + F[NOUT + q];
+    else a.elemF[ef_idx<NOUT>(e, q)] = F[q];
   }
 }
 
 // ---------------------------------------------------------------------------
-// RHS, pass 1 for S3/R3, cooperative streaming form.  Every WAVE is autonomous (no workgroup barrier in the
-// loop, so a wave waiting for memory never holds up another): it walks over groups of 16 consecutive elements,
-// two at a time with 32 lanes per element.  The 2.3 KB of per-element AoS inputs (doubles [112,400) =
-// E_B[24] nu_B[24] fx[8] fy[8] fz[8] gx[72] gy[72] gz[72]) are read as contiguous 16-byte-per-lane runs, two
-// element pairs ahead through registers.  Lane q < 24 owns face Gauss point q (traction sigma.n * face
-// Jacobian, S3:568-648), lane q >= 24 owns volume Gauss point q-24 (w*detJ * f, S3:534-545); then lane
-// (n = q/4, r = q%4) sums the Gauss points p = r mod 4 for the three components of node n and the quad combines
-// its four partial sums.  Fe + Ge of the 16 elements leave as 24 full 128-byte lines of the component-major
-// element-vector array.
+// RHS, pass 1 for S3/R3, 8 lanes per element ("oct" form).  One wave = one workgroup, autonomous, walks groups of
+// 16 consecutive elements, 8 at a time.  The 8 x 2.3 KB of AoS inputs of a step are read as 18 contiguous
+// 16-byte-per-lane runs, one step ahead through registers (indices clamped, never masked: a load under an exec
+// mask or a uniform branch makes the compiler merge old and new register contents through copies behind
+// s_waitcnt vmcnt(0), which serialises the prefetch), and laid out per element in LDS (element stride 296 doubles: conflict-free for the strides 1 and 3 of
+// the per-Gauss-point reads).  Lane j of an element owns the face Gauss points j, j+8, j+16 -- one per face pair,
+// so the three evaluations are straight-line code with the axis a compile-time constant and no lane idles -- and the
+// volume Gauss point j; then lane j = node j sums the 12 face points of its three faces and the 8 volume points.
+// Fe + Ge of 16 elements leave as one contiguous 3 KB block of the element-vector array (ef_idx).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rhs_elem_elastic_coop(const Slab s, const RArgs a) {
-  __shared__ __attribute__((aligned(16))) double sh_in[4][2][288];
-  __shared__ double sh_xc[4][2][24];
-  __shared__ __attribute__((aligned(16))) double sh_w[4][2][32][4];  // 24 face tractions, 8 volume loads
-  __shared__ double sh_C[32][8];                                     // NF[p][n] (p < 24), N[p-24][n]
-  __shared__ double sh_G[8][3][8];
-  __shared__ __attribute__((aligned(16))) double sh_out[4][24][16];
-  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, el = lane >> 5, q = lane & 31;
+template <bool RECT>
+__global__ __launch_bounds__(64) void k_rhs_elem_elastic_oct(const Slab s, const RArgs a) {
+  if ((a.rect != 0 && a.bad[3] == 0ULL) != RECT) return;
+  constexpr int S = 296;                 // doubles per element in sh_in
+  constexpr int W01S = 40, W2S = 40;     // per-element strides of the traction arrays (double2 / double units)
+  __shared__ __attribute__((aligned(16))) double sh_in[8 * S];  // inputs; reused for the tractions once consumed
+  __shared__ __attribute__((aligned(16))) double sh_xc[8][RECT ? 8 : 24];
+  __shared__ __attribute__((aligned(16))) double sh_out[24][16];
+  __shared__ double sh_G[RECT ? 1 : 8][3][8];
+  const int lane = threadIdx.x, x = lane >> 3, j = lane & 7;
   const int64_t M = s.dim[0], N = s.dim[1];
   const int64_t mx = M - 1, my = N - 1;
   const int64_t ngroups = (a.nel + 15) >> 4;
-  const bool aos = a.mat_layout == 0;
-  const bool wide = (a.mat_stride & 1) == 0;  // element blocks keep the base's 16-byte alignment
-  // the reference tables go to LDS: a table read from memory inside the loop would queue behind the prefetch
-  // (loads of one wave return in order)
-  if (tid < 64) sh_C[24 + (tid >> 3)][tid & 7] = c_tab3.N[tid >> 3][tid & 7];
-  else sh_C[(tid - 64) >> 3][tid & 7] = c_tab3.NF[(tid - 64) >> 3][tid & 7];
-  if (tid < 192) (&sh_G[0][0][0])[tid] = (&c_tab3.G[0][0][0])[tid];
-  __syncthreads();
-
-  PH_DECL;
-  // two register sets, one per parity of the pair index: what a step commits was requested two steps earlier
-  double2 pins[2][5];
-  double pxcs[2] = {0.0, 0.0};
+  if constexpr (!RECT) {
+    for (int t = lane; t < 192; t += 64) (&sh_G[0][0][0])[t] = (&c_tab3.G[0][0][0])[t];
+  }
+  // sum-phase constants of node j: its face on axis a is xi_a = +1 (Gauss points 8a..8a+3) or -1 (8a+4..8a+7)
+  const int hd[3] = {HDI[j], HDJ[j], HDK[j]};
+  double cff[3][4], cfv[8];
+  int pb[3];
 #pragma unroll
-  for (int h = 0; h < 2; h++)
+  for (int ax = 0; ax < 3; ax++) {
+    pb[ax] = 8 * ax + (hd[ax] ? 0 : 4);
 #pragma unroll
-    for (int k = 0; k < 5; k++) pins[h][k] = make_double2(0.0, 0.0);
-  auto request = [&](int64_t e, double2 *pin, double &pxc) {  // inputs of element e -> registers
-    if (e >= a.nel) return;
-    int64_t ex, ey, ez;
-    if (a.nel < (int64_t)1 << 31) {  // 32-bit divisions: a 64-bit one costs more than the rest of the step
-      const uint32_t e32 = (uint32_t)e, mx32 = (uint32_t)mx, my32 = (uint32_t)my;
-      const uint32_t t = e32 / mx32, u = t / my32;
-      ex = e32 - t * mx32;
-      ey = t - u * my32;
-      ez = s.els + u;
-    } else {
-      const int64_t t = e / mx;
-      ex = e % mx;
-      ey = t % my;
-      ez = s.els + t / my;
-    }
-    if (q < 24) {
-      const int n = q / 3, d = q % 3;
-      const int64_t node = (ex + HDI[n]) + M * ((ey + HDJ[n]) + N * (ez + HDK[n] - s.cks));
-      pxc = a.coords[3 * node + d];
-    }
-    if (aos) {
-      const double *pr = a.gp + (ex + mx * (ey + my * (ez - s.mat_e_ks))) * a.mat_stride + 112;
-      if (wide) {
-        const double2 *src = reinterpret_cast<const double2 *>(pr);
+    for (int m = 0; m < 4; m++) cff[ax][m] = c_tab3.NF[pb[ax] + m][j];
+  }
 #pragma unroll
-        for (int k = 0; k < 5; k++)
-          if (q + 32 * k < 144) pin[k] = src[q + 32 * k];
-      } else {
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-          const int i0 = 2 * (q + 32 * k);
-          if (i0 < 288) pin[k] = make_double2(pr[i0], pr[i0 + 1]);
-        }
-      }
-    }
-  };
-  auto wave_sync = [&]() {  // LDS written by this wave, read by other lanes of this wave: in order in hardware
+  for (int m = 0; m < 8; m++) cfv[m] = c_tab3.N[m][j];
+  // which coordinate this lane fetches: RECT: lanes 0..5 = x(node 0), x(node 3), y(0), y(1), z(0), z(4); else node j
+  int64_t cofs;
+  if constexpr (RECT) {
+    const int64_t nofs = (j == 1) ? 1 : (j == 3) ? M : (j == 5) ? M * N : 0;
+    cofs = 3 * nofs + ((j < 6) ? (j >> 1) : 0);
+  } else {
+    cofs = 3 * (HDI[j] + M * (HDJ[j] + N * (int64_t)HDK[j]));
+  }
+  const int64_t eoff = mx * my * (s.els - s.mat_e_ks);  // element e of this slab is record e + eoff of the array
+  const int st2 = a.mat_stride >> 1;                    // record stride in double2 units (even strides only)
+  const double side = (j & 4) ? -1.0 : 1.0;             // S3:623-641: Gauss points 4..7 of a face pair are on xi = -1
+  auto wave_sync = [&]() {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
   };
 
-  const int64_t gstride = (int64_t)gridDim.x * 4;
-  int64_t g = (int64_t)blockIdx.x * 4 + w;
-  if (g < ngroups) {
-    request(16 * g + el, pins[0], pxcs[0]);
-    request(16 * g + 2 + el, pins[1], pxcs[1]);
-  }
-  for (; g < ngroups; g += gstride) {
-#pragma unroll 1
-    for (int it2 = 0; it2 < 4; it2++) {
+  double2 pin[18];
+  double pxc[RECT ? 1 : 3];
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const int it = 2 * it2 + h;  // element pair of the group
-        double2 *pin = pins[h];
-        double &pxc = pxcs[h];
-        const int64_t e = 16 * g + 2 * it + el;
-        const bool live = e < a.nel;
-        PH_T(0);
-        if (q < 24) sh_xc[w][el][q] = pxc;
-        {
-          double2 *dst = reinterpret_cast<double2 *>(sh_in[w][el]);
+  for (int k = 0; k < 18; k++) pin[k] = make_double2(0.0, 0.0);
 #pragma unroll
-          for (int k = 0; k < 5; k++)
-            if (q + 32 * k < 144) dst[q + 32 * k] = pin[k];
-        }
-        PH_ACC(0, 1);
-        {  // two pairs ahead: same group, or the first pairs of this wave's next group
-          const int64_t en = (it < 6) ? 16 * g + 2 * (it + 2) : 16 * (g + gstride) + 2 * (it - 6);
-          if (en < 16 * ngroups) request(en + el, pin, pxc);
-        }
-        PH_ACC(1, 2);
-        wave_sync();
-        if (live) {
-          const double *xc = sh_xc[w][el];
-          const double *in = sh_in[w][el];
-          if (q < 24) {
-            double sn[3] = {0.0, 0.0, 0.0};
-            if (aos) {
-              const double dx = fabs(xc[0] - xc[9]), dy = fabs(xc[1] - xc[4]), dz = fabs(xc[2] - xc[14]);
-              const double *gx = in + 72, *gy = in + 144, *gz = in + 216;
-              const double pe = in[q], pn = in[24 + q];
-              const double factor = pe * (1 - pn) / ((1.0 + pn) * (1.0 - 2.0 * pn));
-              const double d11 = factor * 1.0, d12 = factor * (pn / (1 - pn)), d44 = factor * (0.5 * (1 - 2 * pn) / (1 - pn));
-              const double e0 = gx[3 * q], e1 = gy[3 * q + 1], e2 = gz[3 * q + 2];
-              const double e3 = gx[3 * q + 1] + gy[3 * q], e4 = gy[3 * q + 2] + gz[3 * q + 1], e5 = gx[3 * q + 2] + gz[3 * q];
-              const double z0 = d11 * e0 + d12 * e1 + d12 * e2;
-              const double z1 = d12 * e0 + d11 * e1 + d12 * e2;
-              const double z2 = d12 * e0 + d12 * e1 + d11 * e2;
-              const double z3 = d44 * e3, z4 = d44 * e4, z5 = d44 * e5;
-              const int axis = q >> 3;
-              const double side = ((q >> 2) & 1) ? -1.0 : 1.0;
-              double Jp;
-              if (axis == 0)      { sn[0] = z0 * side; sn[1] = z3 * side; sn[2] = z5 * side; Jp = (0.5 * dy) * (0.5 * dz); }
-              else if (axis == 1) { sn[0] = z3 * side; sn[1] = z1 * side; sn[2] = z4 * side; Jp = (0.5 * dx) * (0.5 * dz); }
-              else                { sn[0] = z5 * side; sn[1] = z4 * side; sn[2] = z2 * side; Jp = (0.5 * dx) * (0.5 * dy); }
-              const double fac = 1.0 * Jp;
+  for (int d = 0; d < (RECT ? 1 : 3); d++) pxc[d] = 0.0;
+  auto request = [&](int64_t e0, double2 *pin, double *pxc) {  // inputs of elements e0 .. e0+7 -> registers
+    if (e0 > a.nel - 1) e0 = a.nel - 1;
+    const int xmax = (int)((a.nel - 1 - e0 < 7) ? a.nel - 1 - e0 : 7);
+    const double2 *blk = reinterpret_cast<const double2 *>(a.gp + (e0 + eoff) * a.mat_stride + 112);
 #pragma unroll
-              for (int c = 0; c < 3; c++) sn[c] *= fac;
-            }
-#pragma unroll
-            for (int c = 0; c < 3; c++) sh_w[w][el][q][c] = sn[c];
-          } else {
-            const int p = q - 24;
-            double u[3] = {0.0, 0.0, 0.0};
-            if (aos) {
-              const double fac = 1.0 * det3_only(sh_G[p], xc);
-              u[0] = fac * in[48 + p];
-              u[1] = fac * in[56 + p];
-              u[2] = fac * in[64 + p];
-            }
-#pragma unroll
-            for (int c = 0; c < 3; c++) sh_w[w][el][q][c] = u[c];
-          }
-        }
-        PH_ACC(2, 3);
-        wave_sync();
-        {
-          const int n = q >> 2, r = q & 3;
-          double o[3] = {0.0, 0.0, 0.0};
-          if (live) {
-#pragma unroll
-            for (int pp = 0; pp < 8; pp++) {
-              const int p = r + 4 * pp;
-              const double cf = sh_C[p][n];
-              const double2 w01 = *reinterpret_cast<const double2 *>(&sh_w[w][el][p][0]);
-              const double w2 = sh_w[w][el][p][2];
-              o[0] = fma(cf, w01.x, o[0]);
-              o[1] = fma(cf, w01.y, o[1]);
-              o[2] = fma(cf, w2, o[2]);
-            }
-          }
-#pragma unroll
-          for (int c = 0; c < 3; c++) {
-            o[c] += __shfl_xor(o[c], 1);
-            o[c] += __shfl_xor(o[c], 2);
-          }
-          if (r < 3) sh_out[w][3 * n + r][2 * it + el] = o[r];
-        }
-        PH_ACC(3, 4);
-        wave_sync();  // sh_w / sh_in / sh_xc are rewritten by the next pair
-      }
+    for (int k = 0; k < 18; k++) {
+      const int c = 64 * k + lane, xe = c / 144, r = c - 144 * xe;
+      pin[k] = blk[(xe < xmax ? xe : xmax) * st2 + r];
     }
+#if FEMASM_EXP >= 5
+    pxc[0] = 0.0;
+    return;
+#endif
+    const uint32_t e32 = (uint32_t)(e0 + (x < xmax ? x : xmax));  // (the host keeps nel below 2^31 for this kernel)
+    const uint32_t t = e32 / (uint32_t)mx, u = t / (uint32_t)my;
+    const int64_t ex = e32 - t * (uint32_t)mx, ey = t - u * (uint32_t)my, ez = s.els + u;
+    const double *cn = a.coords + 3 * (ex + M * (ey + N * (ez - s.cks))) + cofs;
+    pxc[0] = cn[0];
+    if constexpr (!RECT) {
+      pxc[1] = cn[1];
+      pxc[2] = cn[2];
+    }
+  };
+
+  // The finished group leaves one step late, right after the next commit and BEFORE the next request: a wave's
+  // memory operations retire in order, so a store issued after a load makes the wait for that load wait for the
+  // store's acknowledgement as well (measured: 0.27 ms of 1.12 ms with the stores at the end of the group).
+  auto store_group = [&](int64_t gs) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) {  // 24 lines of 16 elements, 16 bytes per lane
+    for (int k = 0; k < 3; k++) {  // one contiguous 3 KB block, 16 bytes per lane
       const int idx = lane + 64 * k, t = idx >> 3, part = idx & 7;
-      *reinterpret_cast<double2 *>(a.elemF + t * a.nelp + 16 * g + 2 * part) =
-          *reinterpret_cast<const double2 *>(&sh_out[w][t][2 * part]);
+      *reinterpret_cast<double2 *>(a.elemF + (gs * 24 + t) * 16 + 2 * part) =
+          *reinterpret_cast<const double2 *>(&sh_out[t][2 * part]);
     }
-    wave_sync();
+  };
+  int64_t g = blockIdx.x, gprev = -1;
+  if (g < ngroups) request(16 * g, pin, pxc);
+  for (; g < ngroups; g += gridDim.x) {
+#pragma unroll 1
+    for (int half = 0; half < 2; half++) {
+      // commit the step's inputs, then ask for the next step's
+      {
+        double2 *dst = reinterpret_cast<double2 *>(sh_in);
+#pragma unroll
+        for (int k = 0; k < 18; k++) {
+          const int c = 64 * k + lane, xe = c / 144, r = c - 144 * xe;
+          dst[xe * (S / 2) + r] = pin[k];
+        }
+        if constexpr (RECT) {
+          sh_xc[x][j] = pxc[0];
+        } else {
+#pragma unroll
+          for (int d = 0; d < 3; d++) sh_xc[x][3 * j + d] = pxc[d];
+        }
+      }
+      if (half == 0 && gprev >= 0) store_group(gprev);
+      request(half == 0 ? 16 * g + 8 : 16 * (g + gridDim.x), pin, pxc);
+      wave_sync();
+      const double *in = sh_in + x * S;
+#if FEMASM_EXP >= 4  // skeleton: the input stream and the output lines only
+      {
+        const double v = in[j] + in[24 + j] + sh_xc[x][j & 3];
+        wave_sync();
+#pragma unroll
+        for (int c = 0; c < 3; c++) sh_out[3 * j + c][8 * half + x] = v;
+        wave_sync();
+        continue;
+      }
+#endif
+      double dx, dy, dz;
+      if constexpr (RECT) {
+        const double2 cx = *reinterpret_cast<const double2 *>(&sh_xc[x][0]);
+        const double2 cy = *reinterpret_cast<const double2 *>(&sh_xc[x][2]);
+        const double2 cz = *reinterpret_cast<const double2 *>(&sh_xc[x][4]);
+        dx = fabs(cx.x - cx.y); dy = fabs(cy.x - cy.y); dz = fabs(cz.x - cz.y);
+      } else {
+        const double *xc = sh_xc[x];
+        dx = fabs(xc[0] - xc[9]); dy = fabs(xc[1] - xc[4]); dz = fabs(xc[2] - xc[14]);  // S3:560-562
+      }
+      double sn[3][3], u[3];
+#pragma unroll
+      for (int ax = 0; ax < 3; ax++) {  // face Gauss point p = j + 8 ax: traction sigma.n * face Jacobian, S3:568-648
+        const int p = j + 8 * ax;
+        const double pe = in[p], pn = in[24 + p];
+        const double t = pe / ((1.0 + pn) * (1.0 - 2.0 * pn));  // S3:585-593 with one division
+        const double d11 = t * (1 - pn), d12 = t * pn, d44 = t * (0.5 * (1 - 2 * pn));
+        const double *gx = in + 72 + 3 * p, *gy = in + 144 + 3 * p, *gz = in + 216 + 3 * p;
+        const double e0 = gx[0], e1 = gy[1], e2 = gz[2];
+        const double e3 = gx[1] + gy[0], e4 = gy[2] + gz[1], e5 = gx[2] + gz[0];
+        const double z0 = d11 * e0 + d12 * e1 + d12 * e2;
+        const double z1 = d12 * e0 + d11 * e1 + d12 * e2;
+        const double z2 = d12 * e0 + d12 * e1 + d11 * e2;
+        const double z3 = d44 * e3, z4 = d44 * e4, z5 = d44 * e5;
+        double Jp;
+        if (ax == 0)      { sn[ax][0] = z0 * side; sn[ax][1] = z3 * side; sn[ax][2] = z5 * side; Jp = (0.5 * dy) * (0.5 * dz); }
+        else if (ax == 1) { sn[ax][0] = z3 * side; sn[ax][1] = z1 * side; sn[ax][2] = z4 * side; Jp = (0.5 * dx) * (0.5 * dz); }
+        else              { sn[ax][0] = z5 * side; sn[ax][1] = z4 * side; sn[ax][2] = z2 * side; Jp = (0.5 * dx) * (0.5 * dy); }
+        const double fac = 1.0 * Jp;
+#pragma unroll
+        for (int c = 0; c < 3; c++) sn[ax][c] *= fac;
+      }
+      {  // volume Gauss point j: w detJ f, S3:534-545
+        double fac;
+        if constexpr (RECT) fac = 1.0 * ((0.5 * dx) * (0.5 * dy) * (0.5 * dz));
+        else fac = 1.0 * det3_only(sh_G[j], sh_xc[x]);
+        u[0] = fac * in[48 + j];
+        u[1] = fac * in[56 + j];
+        u[2] = fac * in[64 + j];
+      }
+      wave_sync();  // every lane has consumed its inputs: the region is reused for the tractions
+      double2 *w01 = reinterpret_cast<double2 *>(sh_in) + x * W01S;  // [element][32 Gauss points] (c = 0,1)
+      double *w2 = sh_in + 2 * 8 * W01S + x * W2S;                   // [element][32] (c = 2)
+#pragma unroll
+      for (int ax = 0; ax < 3; ax++) {
+        w01[j + 8 * ax] = make_double2(sn[ax][0], sn[ax][1]);
+        w2[j + 8 * ax] = sn[ax][2];
+      }
+      w01[24 + j] = make_double2(u[0], u[1]);
+      w2[24 + j] = u[2];
+      wave_sync();
+      double o[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ax = 0; ax < 3; ax++)
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          const double2 v = w01[pb[ax] + m];
+          const double v2 = w2[pb[ax] + m];
+          o[0] = fma(cff[ax][m], v.x, o[0]);
+          o[1] = fma(cff[ax][m], v.y, o[1]);
+          o[2] = fma(cff[ax][m], v2, o[2]);
+        }
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const double2 v = w01[24 + m];
+        const double v2 = w2[24 + m];
+        o[0] = fma(cfv[m], v.x, o[0]);
+        o[1] = fma(cfv[m], v.y, o[1]);
+        o[2] = fma(cfv[m], v2, o[2]);
+      }
+#pragma unroll
+      for (int c = 0; c < 3; c++) sh_out[3 * j + c][8 * half + x] = o[c];
+      wave_sync();  // sh_in is rewritten by the next step's commit
+    }
+    gprev = g;
   }
-  PH_FLUSH(24);
+  if (gprev >= 0) store_group(gprev);
 }
 
 // ---------------------------------------------------------------------------
@@ -1024,7 +1047,7 @@ __global__ __launch_bounds__(256) void k_op_elem(const Slab s, const RArgs a, do
     }
   }
 #pragma unroll
-  for (int q = 0; q < NEN * DOF; q++) a.elemF[q * a.nelp + e] = F[q];
+  for (int q = 0; q < NEN * DOF; q++) a.elemF[ef_idx<NEN * DOF>(e, q)] = F[q];
 }
 
 // ---------------------------------------------------------------------------
@@ -1058,20 +1081,20 @@ __global__ __launch_bounds__(256) void k_rhs_gather(const Slab s, const RArgs a)
         for (int ox = -1; ox <= 0; ox++) {
           const int64_t ex = i + ox, ey = j + oy, ez = k + oz;
           if (ex < 0 || ex >= mx || ey < 0 || ey >= my || ez < s.els || ez >= s.ele) continue;
-          const double *F = a.elemF + (e111 + ox + mx * (oy + my * oz));
+          const double *F = a.elemF + ef_idx<T::NEN * DOF>(e111 + ox + mx * (oy + my * oz), 0);
           const int al = hex_idx(-ox, -oy, -oz);
 #pragma unroll
-          for (int c = 0; c < DOF; c++) b[c] = b[c] + F[(al * DOF + c) * a.nelp];
+          for (int c = 0; c < DOF; c++) b[c] = b[c] + F[(al * DOF + c) * 16];
         }
   } else {
     for (int oy = -1; oy <= 0; oy++)
       for (int ox = -1; ox <= 0; ox++) {
         const int64_t ex = i + ox, ey = j + oy;
         if (ex < 0 || ex >= mx || ey < s.els || ey >= s.ele) continue;
-        const double *F = a.elemF + (ex + mx * (ey - s.els));
+        const double *F = a.elemF + ef_idx<T::NEN * DOF>(ex + mx * (ey - s.els), 0);
         const int al = quad_idx(-ox, -oy);
 #pragma unroll
-        for (int c = 0; c < DOF; c++) b[c] = b[c] + F[(al * DOF + c) * a.nelp];
+        for (int c = 0; c < DOF; c++) b[c] = b[c] + F[(al * DOF + c) * 16];
       }
   }
 
@@ -1159,7 +1182,10 @@ __global__ __launch_bounds__(256) void k_check_rectilinear(const Slab s, const d
       bad |= v != ref;
     }
   }
-  if (__ballot(bad) != 0ULL && (threadIdx.x & 63) == 0) atomicAdd(flag, 1ULL);
+  if (__ballot(bad) != 0ULL && (threadIdx.x & 63) == 0) {
+    atomicAdd(flag, 1ULL);      // bad[1]: premise of the level-2 stiffness kernels
+    atomicAdd(flag + 2, 1ULL);  // bad[3]: the mesh is not rectilinear (read by the RHS element pass)
+  }
 }
 
 // ---------------------------------------------------------------------------

@@ -29,6 +29,82 @@ __global__ __launch_bounds__(256) void rd(const double *gp, int64_t nel, double 
   }
   if (acc.x == 123.456) sink[0] = acc.y;
 }
+// the RHS kernel's traversal: every wave owns groups of 16 consecutive elements and walks them two elements at a
+// time (32 lanes each), two pairs ahead; MODE 0: consecutive waves own consecutive groups (a wave's reads are 6.4 KB
+// chunks 51 KB apart from its neighbours'); MODE 1: the 4 waves of a workgroup share 64 consecutive elements and read
+// 8 consecutive elements per step (25.6 KB chunks)
+template <int MODE>
+__global__ __launch_bounds__(256) void coop(const double *gp, int64_t nel, double *sink, double *out = nullptr, int wmode = 0) {
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, el = lane >> 5, q = lane & 31;
+  const int qk4 = (q + 128 < 144) ? q + 128 : 143;
+  double2 acc = make_double2(0, 0);
+  double2 pins[2][5];
+  auto req = [&](int64_t e, double2 *pin) {
+    if (e >= nel) e = nel - 1;
+    const double2 *src = reinterpret_cast<const double2 *>(gp + e * 400 + 112);
+#pragma unroll
+    for (int k = 0; k < 4; k++) pin[k] = src[q + 32 * k];
+    pin[4] = src[qk4];
+  };
+  const int64_t ngroups = nel / 16;
+  if (MODE == 0) {
+    const int64_t gstride = (int64_t)gridDim.x * 4;
+    int64_t g = (int64_t)blockIdx.x * 4 + w;
+    req(16 * g + el, pins[0]);
+    req(16 * g + 2 + el, pins[1]);
+    for (; g < ngroups; g += gstride)
+#pragma unroll 1
+      for (int it2 = 0; it2 < 4; it2++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int it = 2 * it2 + h;
+#pragma unroll
+          for (int k = 0; k < 5; k++) { acc.x += pins[h][k].x; acc.y += pins[h][k].y; }
+          const int64_t en = (it < 6) ? 16 * g + 2 * (it + 2) : 16 * (g + gstride) + 2 * (it - 6);
+          req(en + el, pins[h]);
+          if (out && it == 7) {  // the element vectors of the group: 3 KB
+            if (wmode == 0) {      // one contiguous block per group
+#pragma unroll
+              for (int k = 0; k < 3; k++) *reinterpret_cast<double2 *>(out + g * 384 + (lane + 64 * k) * 2) = acc;
+            } else if (wmode == 2) {  // contiguous block, non-temporal
+#pragma unroll
+              for (int k = 0; k < 3; k++) {
+                double *o = out + g * 384 + (lane + 64 * k) * 2;
+                __builtin_nontemporal_store(acc.x, o);
+                __builtin_nontemporal_store(acc.y, o + 1);
+              }
+            } else if (wmode == 3) {  // contiguous block, only every 4th group writes 4x the data (same bytes, burstier)
+              if ((g / gstride) % 4 == 3)
+#pragma unroll
+                for (int k = 0; k < 12; k++) *reinterpret_cast<double2 *>(out + (g / gstride / 4 * gstride + g % gstride) * 1536 + (lane + 64 * k) * 2) = acc;
+            } else if (wmode == 1) {  // 24 rows 16 MiB apart (component-major)
+#pragma unroll
+              for (int k = 0; k < 3; k++) {
+                const int idx = lane + 64 * k, t = idx >> 3, part = idx & 7;
+                *reinterpret_cast<double2 *>(out + t * (int64_t)2097152 + 16 * g + 2 * part) = acc;
+              }
+            }
+          }
+        }
+  } else {
+    const int64_t bstride = (int64_t)gridDim.x * 64;
+    int64_t b = (int64_t)blockIdx.x * 64;
+    req(b + 2 * w + el, pins[0]);
+    req(b + 8 + 2 * w + el, pins[1]);
+    for (; b < nel; b += bstride)
+#pragma unroll 1
+      for (int it2 = 0; it2 < 4; it2++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int it = 2 * it2 + h;
+#pragma unroll
+          for (int k = 0; k < 5; k++) { acc.x += pins[h][k].x; acc.y += pins[h][k].y; }
+          const int64_t en = (it < 6) ? b + 8 * (it + 2) : b + bstride + 8 * (it - 6);
+          req(en + 2 * w + el, pins[h]);
+        }
+  }
+  if (acc.x == 123.456) sink[0] = acc.y;
+}
 // plain linear read
 __global__ void lin(const double2 *p, int64_t n2, double *sink) {
   double2 acc = make_double2(0, 0);
@@ -50,14 +126,21 @@ void timeit(const char *name, double bytes, F launch) {
 int main() {
   const int64_t nel = 2097152;
   double *gp, *sink; hipMalloc(&gp, nel * 400 * 8); hipMalloc(&sink, 64);
+  double *outb; hipMalloc(&outb, (size_t)24 * 2097152 * 8 + 4096);
   hipMemset(gp, 0x3f, nel * 400 * 8);  // non-zero bytes
   const double b288 = nel * 288.0 * 8, b400 = nel * 400.0 * 8;
-  for (int wg : {4, 8}) {
+  for (int wg : {3, 8}) {
     printf("--- %d WG/CU ---\n", wg);
     timeit("linear 16B/lane, whole array", b400, [&] { lin<<<256 * wg, 256>>>((const double2 *)gp, nel * 200, sink); });
     timeit("records [112,400), 1 element ahead", b288, [&] { rd<1><<<256 * wg, 256>>>(gp, nel, sink, 112); });
     timeit("records [112,400), 2 ahead", b288, [&] { rd<2><<<256 * wg, 256>>>(gp, nel, sink, 112); });
     timeit("records [112,400), 4 ahead", b288, [&] { rd<4><<<256 * wg, 256>>>(gp, nel, sink, 112); });
+    timeit("coop traversal, wave-owned groups of 16", b288, [&] { coop<0><<<256 * wg, 256>>>(gp, nel, sink); });
+    timeit("coop traversal + 3 KB block stores per group", b288, [&] { coop<0><<<256 * wg, 256>>>(gp, nel, sink, outb, 0); });
+    timeit("coop traversal + block stores, non-temporal", b288, [&] { coop<0><<<256 * wg, 256>>>(gp, nel, sink, outb, 2); });
+    timeit("coop traversal + 12 KB stores every 4th group", b288, [&] { coop<0><<<256 * wg, 256>>>(gp, nel, sink, outb, 3); });
+    timeit("coop traversal + component-major stores", b288, [&] { coop<0><<<256 * wg, 256>>>(gp, nel, sink, outb, 1); });
+    timeit("coop traversal, workgroup-owned 64, 8 consecutive/step", b288, [&] { coop<1><<<256 * wg, 256>>>(gp, nel, sink); });
     timeit("records [0,400) whole, 2 ahead (bytes=400)", b400, [&] { rd<2><<<256 * wg, 256>>>(gp, nel, sink, 0); });
   }
   return 0;

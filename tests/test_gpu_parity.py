@@ -684,3 +684,40 @@ def test_rigid_body_modes(env, kind, dims):
         parts.append(out.reshape(nm, -1))
         pl.close()
     assert np.abs(np.concatenate(parts, axis=1) - ref).max() < 1e-12
+
+
+@pytest.mark.parametrize("stride,shift", [(401, 0), (400, 1), (402, 0)])
+def test_elastic_rhs_odd_stride_or_base_takes_the_per_element_kernel(env, stride, shift):
+    """The streaming RHS kernel reads 16-byte runs; an odd stride or an 8-byte-aligned base must still give the
+    same b (host routes them to the thread-per-element kernel)."""
+    torch, F, dev, O = env["torch"], env["F"], env["dev"], env["O"]
+    case = make_case(env, "s3", (6, 5, 4), vary_material=True)
+    M, N, P = case["dims"]
+    nel = (M - 1) * (N - 1) * (P - 1)
+    wide = np.zeros((nel, stride))
+    wide[:, :400] = case["props"].reshape(nel, 400)
+    buf = torch.zeros(nel * stride + shift, dtype=torch.float64, device=dev)
+    buf[shift:] = torch.from_numpy(wide.reshape(-1)).to(dev)
+    plan = F.Plan(F.ELASTIC3D_Q1, M, N, P, coords=torch.from_numpy(case["coords"]).to(dev))
+    vals = torch.empty(plan.nnz, dtype=torch.float64, device=dev)
+    b = torch.empty(plan.nrows, dtype=torch.float64, device=dev)
+    plan.assemble_system(vals, b, material=buf[shift:], stride=stride, bc=F.BC_S3_ALLFACES_EXACT)
+    assert rel(vals.cpu().numpy(), case["K"]) <= TOL and rel(b.cpu().numpy(), case["b"]) <= TOL
+    plan.close()
+
+
+def test_elastic_uniform_material_rhs_is_the_dirichlet_data(env):
+    """FEMASM_MAT_UNIFORM carries no loads: b holds only the Dirichlet values (zero body force, no traction)."""
+    torch, F, dev, O = env["torch"], env["F"], env["dev"], env["O"]
+    M, N, P = 5, 6, 4
+    coords = O.uniform_coords(3, M, N, P)
+    rp, ci = O.pattern(3, 3, M, N, P)
+    props = O.props_s3(M - 1, N - 1, P - 1, coords).reshape(-1, 400)
+    props[:, 160:400] = 0.0  # fx,fy,fz,gx,gy,gz
+    K, bref = O.assemble_elastic3d(M, N, P, coords, props.reshape(-1), rp, ci)
+    O.bc_s3(M, N, P, coords, rp, ci, K, bref)
+    plan = F.Plan(F.ELASTIC3D_Q1, M, N, P, coords=torch.from_numpy(coords).to(dev))
+    b = torch.full((plan.nrows,), float("nan"), dtype=torch.float64, device=dev)
+    plan.assemble_system(None, b, material=None, E=90.0, nu=0.28, bc=F.BC_S3_ALLFACES_EXACT)
+    assert np.abs(b.cpu().numpy() - bref).max() <= 1e-15
+    plan.close()
