@@ -74,6 +74,7 @@ struct femasm_plan {
   // RHS scratch: per-element Fe (Ge)
   double *elemF = nullptr;
   int64_t nelp = 0;                    // nel rounded up to whole blocks of 16 elements
+  int64_t elemF_count = 0;             // doubles allocated in elemF
   // interface buffers (K rows of one node layer in CSR layout, then the b slice)
   double *send = nullptr, *recv = nullptr;
   int64_t send_count = 0, recv_count = 0, send_nnz = 0, recv_nnz = 0;
@@ -294,27 +295,30 @@ int launch_rhs(femasm_plan *p, const femasm_material *mat, int bc, double *out, 
   a.iface = iface;
   a.bad = p->bad;
   a.rect = p->rect_checked ? 1 : 0;
+  // S3/R3 with the reference's AoS records as 16-byte runs: streaming element pass + in-wave part of the node sum
+  // (k_rhs_elem_elastic_runs); anything else (uniform material: no loads; an odd stride or base) takes the
+  // thread-per-element kernel and the element-vector form of the gather
+  const int64_t nlay = sl.ele - sl.els;
+  const int64_t ntasks = ((nlay + RUNS_ZC - 1) / RUNS_ZC) * (p->s.dim[1] - 1) * ((p->s.dim[0] - 1 + 15) / 16);
+  const bool runs = KIND == KIND_ELASTIC && a.gp && (a.mat_stride & 1) == 0 && ((uintptr_t)a.gp & 15) == 0 &&
+                    ntasks < ((int64_t)1 << 31) && ntasks * (RUNS_ZC + 1) * 128 <= p->elemF_count;
+  a.runs = runs ? 1 : 0;
   if (do_elem && nel > 0) {
-    // the cooperative streaming kernel reads the AoS records as 16-byte runs; anything else (uniform material:
-    // no loads, or an odd stride / odd base) takes the thread-per-element kernel
-    const bool coop = KIND == KIND_ELASTIC && a.gp && (a.mat_stride & 1) == 0 && ((uintptr_t)a.gp & 15) == 0 &&
-                      nel < ((int64_t)1 << 31);
-    if (coop) {
-      // persistent one-wave workgroups: exactly one resident set, so that every one walks the same number of groups
+    if (runs) {
+      // persistent one-wave workgroups: one resident set
       static int wg_per_cu[2] = {0, 0}, ncu = 0;
       if (!wg_per_cu[0]) {
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, p->device));
         ncu = prop.multiProcessorCount;
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu[1], k_rhs_elem_elastic_oct<true>, 64, 0));
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu[0], k_rhs_elem_elastic_oct<false>, 64, 0));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu[1], k_rhs_elem_elastic_runs<true>, 64, 0));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu[0], k_rhs_elem_elastic_runs<false>, 64, 0));
         if (wg_per_cu[0] < 1) wg_per_cu[0] = 1;
         if (wg_per_cu[1] < 1) wg_per_cu[1] = 1;
       }
-      const int64_t ngroups = (nel + 15) / 16;
-      auto grid = [&](int v) { const int64_t r = (int64_t)ncu * wg_per_cu[v]; return dim3((unsigned)(ngroups < r ? ngroups : r)); };
-      if (a.rect) hipLaunchKernelGGL(k_rhs_elem_elastic_oct<true>, grid(1), dim3(64), 0, p->stream, sl, a);
-      hipLaunchKernelGGL(k_rhs_elem_elastic_oct<false>, grid(0), dim3(64), 0, p->stream, sl, a);
+      auto grid = [&](int v) { const int64_t r = (int64_t)ncu * wg_per_cu[v]; return dim3((unsigned)(ntasks < r ? ntasks : r)); };
+      if (a.rect) hipLaunchKernelGGL(k_rhs_elem_elastic_runs<true>, grid(1), dim3(64), 0, p->stream, sl, a);
+      hipLaunchKernelGGL(k_rhs_elem_elastic_runs<false>, grid(0), dim3(64), 0, p->stream, sl, a);
     }
     else
       hipLaunchKernelGGL(k_rhs_elem<KIND>, dim3(nblk(nel)), dim3(256), 0, p->stream, sl, a);
@@ -322,7 +326,12 @@ int launch_rhs(femasm_plan *p, const femasm_material *mat, int bc, double *out, 
   }
   const dim3 ggrid = (T::NSD == 3) ? dim3(nblk(p->s.dim[0]), (unsigned)p->s.dim[1], (unsigned)(s1 - s0))
                                    : dim3(nblk(p->s.dim[0]), (unsigned)(s1 - s0), 1);
-  hipLaunchKernelGGL(k_rhs_gather<KIND>, ggrid, dim3(256), 0, p->stream, sl, a);
+  if constexpr (KIND == KIND_ELASTIC) {
+    if (runs) hipLaunchKernelGGL((k_rhs_gather<KIND_ELASTIC, true>), ggrid, dim3(256), 0, p->stream, sl, a);
+    else hipLaunchKernelGGL(k_rhs_gather<KIND>, ggrid, dim3(256), 0, p->stream, sl, a);
+  } else {
+    hipLaunchKernelGGL(k_rhs_gather<KIND>, ggrid, dim3(256), 0, p->stream, sl, a);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -425,7 +434,13 @@ int femasm_plan_create(const femasm_mesh *mesh, const femasm_quad *quad, int dev
   PCHK(hipMemsetAsync(p->bad, 0, 32 * sizeof(unsigned long long), p->stream));
   // element vectors: blocks of 16 elements x nen*dof lines (ef_idx in femasm_kernels.h)
   p->nelp = ((p->nel > 0 ? p->nel : 1) + 15) & ~(int64_t)15;
-  PCHK(hipMalloc(&p->elemF, (size_t)p->nelp * nen * dof * sizeof(double)));
+  p->elemF_count = p->nelp * nen * dof;
+  if (p->kind == KIND_ELASTIC) {  // or the records of the runs kernel (femasm_kernels.h), whichever is larger
+    const int64_t nlay = p->s.ele - p->s.els;
+    const int64_t recs = ((nlay + RUNS_ZC - 1) / RUNS_ZC) * (N - 1) * ((M - 1 + 15) / 16) * (RUNS_ZC + 1) * 128;
+    if (recs > p->elemF_count) p->elemF_count = recs;
+  }
+  PCHK(hipMalloc(&p->elemF, (size_t)p->elemF_count * sizeof(double)));
 
   // interface buffers: rows of node layer ks-1 (owed to the rank below) and of ke-1 (owed to us)
   if (s.ks > 0) {

@@ -593,6 +593,7 @@ struct RArgs {
   unsigned long long *bad;  // plan flags / profiling counters
   const double *x;          // N4 operator apply: input vector on the node layers of coords (else null)
   int32_t rect;             // the rectilinearity pre-pass ran in this call: bad[3] == 0 <=> every element is a box
+  int32_t runs;             // elemF holds the records of k_rhs_elem_elastic_runs, not element vectors
 };
 
 template <int KIND>
@@ -729,33 +730,43 @@ __global__ __launch_bounds__(256) void k_rhs_elem(const Slab s, const RArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// RHS, pass 1 for S3/R3, 8 lanes per element ("oct" form).  One wave = one workgroup, autonomous, walks groups of
-// 16 consecutive elements, 8 at a time.  The 8 x 2.3 KB of AoS inputs of a step are read as 18 contiguous
-// 16-byte-per-lane runs, one step ahead through registers (indices clamped, never masked: a load under an exec
-// mask or a uniform branch makes the compiler merge old and new register contents through copies behind
-// s_waitcnt vmcnt(0), which serialises the prefetch), and laid out per element in LDS (element stride 296 doubles: conflict-free for the strides 1 and 3 of
-// the per-Gauss-point reads).  Lane j of an element owns the face Gauss points j, j+8, j+16 -- one per face pair,
-// so the three evaluations are straight-line code with the axis a compile-time constant and no lane idles -- and the
-// volume Gauss point j; then lane j = node j sums the 12 face points of its three faces and the 8 volume points.
-// Fe + Ge of 16 elements leave as one contiguous 3 KB block of the element-vector array (ef_idx).
+// RHS, pass 1 for S3/R3, "runs" form.  One wave = one workgroup, autonomous.  Element pass, 8 lanes per element,
+// 8 elements per step: the 8 x 2.3 KB of AoS inputs (doubles [112,400) = E_B[24] nu_B[24] fx[8] fy[8] fz[8] gx[72]
+// gy[72] gz[72]) are read as 18 contiguous 16-byte-per-lane non-temporal runs, one step ahead through registers
+// (indices clamped, never masked: a load under an exec mask or a uniform branch makes the compiler merge old and
+// new register contents through copies behind s_waitcnt vmcnt(0), which serialises the prefetch), and laid out per
+// element in LDS (element stride 296 doubles: conflict-free for the strides 1 and 3 of the per-Gauss-point reads).
+// Lane j of an element owns the face Gauss points j, j+8, j+16 -- one per face pair, so the three evaluations are
+// straight-line code with the axis a compile-time constant and no lane idles -- and the volume Gauss point j; then
+// lane j = node j sums the 12 face points of its three faces and the 8 volume points (Fe + Ge).
+// Then the part of the node sum that is local to a wave.  Writes that share the memory system with a read stream are expensive on this part (the
+// 0.4 GB of element vectors cost 0.25 ms of the 1.1 ms element pass, whatever their layout or cache policy;
+// scripts/ubench/read_pattern.hip), so a wave keeps a run of 16 x-consecutive elements and walks it through
+// RUNS_ZC element layers: it adds the two elements either side of each of the run's 17 node columns and the two
+// element layers either side of each node layer, and writes, per node layer, 17 x 2 (y side) x 3 partial sums as
+// one 1 KB record -- a third of the bytes.  k_rhs_gather<ELASTIC, true> adds the <= 8 records' entries that meet
+// in a node (2 y sides x run boundary x chunk boundary), in a fixed order.
+// Record of (task, layer l): 128 doubles, entry (c*2 + dy)*20 + X; task = (chunk*my + ey)*nr + run.
 // ---------------------------------------------------------------------------
+constexpr int RUNS_ZC = 32;
 template <bool RECT>
-__global__ __launch_bounds__(64) void k_rhs_elem_elastic_oct(const Slab s, const RArgs a) {
+__global__ __launch_bounds__(64) void k_rhs_elem_elastic_runs(const Slab s, const RArgs a) {
   if ((a.rect != 0 && a.bad[3] == 0ULL) != RECT) return;
-  constexpr int S = 296;                 // doubles per element in sh_in
-  constexpr int W01S = 40, W2S = 40;     // per-element strides of the traction arrays (double2 / double units)
+  constexpr int S = 296, W01S = 40, W2S = 40, ZC = RUNS_ZC;
   __shared__ __attribute__((aligned(16))) double sh_in[8 * S];  // inputs; reused for the tractions once consumed
   __shared__ __attribute__((aligned(16))) double sh_xc[8][RECT ? 8 : 24];
-  __shared__ __attribute__((aligned(16))) double sh_out[24][16];
+  __shared__ __attribute__((aligned(16))) double sh_o[16 * 8 * 3];  // element vectors of the run; then the record
   __shared__ double sh_G[RECT ? 1 : 8][3][8];
   const int lane = threadIdx.x, x = lane >> 3, j = lane & 7;
   const int64_t M = s.dim[0], N = s.dim[1];
   const int64_t mx = M - 1, my = N - 1;
-  const int64_t ngroups = (a.nel + 15) >> 4;
+  const int nlay = (int)(s.ele - s.els);
+  const uint32_t nr = (uint32_t)((mx + 15) >> 4), nzc = (uint32_t)((nlay + ZC - 1) / ZC);
+  const int64_t ntasks = (int64_t)nzc * my * nr;
+  if ((int64_t)blockIdx.x >= ntasks) return;
   if constexpr (!RECT) {
     for (int t = lane; t < 192; t += 64) (&sh_G[0][0][0])[t] = (&c_tab3.G[0][0][0])[t];
   }
-  // sum-phase constants of node j: its face on axis a is xi_a = +1 (Gauss points 8a..8a+3) or -1 (8a+4..8a+7)
   const int hd[3] = {HDI[j], HDJ[j], HDK[j]};
   double cff[3][4], cfv[8];
   int pb[3];
@@ -767,7 +778,6 @@ __global__ __launch_bounds__(64) void k_rhs_elem_elastic_oct(const Slab s, const
   }
 #pragma unroll
   for (int m = 0; m < 8; m++) cfv[m] = c_tab3.N[m][j];
-  // which coordinate this lane fetches: RECT: lanes 0..5 = x(node 0), x(node 3), y(0), y(1), z(0), z(4); else node j
   int64_t cofs;
   if constexpr (RECT) {
     const int64_t nofs = (j == 1) ? 1 : (j == 3) ? M : (j == 5) ? M * N : 0;
@@ -775,13 +785,16 @@ __global__ __launch_bounds__(64) void k_rhs_elem_elastic_oct(const Slab s, const
   } else {
     cofs = 3 * (HDI[j] + M * (HDJ[j] + N * (int64_t)HDK[j]));
   }
-  const int64_t eoff = mx * my * (s.els - s.mat_e_ks);  // element e of this slab is record e + eoff of the array
-  const int st2 = a.mat_stride >> 1;                    // record stride in double2 units (even strides only)
-  const double side = (j & 4) ? -1.0 : 1.0;             // S3:623-641: Gauss points 4..7 of a face pair are on xi = -1
+  const int64_t eoff = mx * my * (s.els - s.mat_e_ks);
+  const int st2 = a.mat_stride >> 1;
+  const double side = (j & 4) ? -1.0 : 1.0;
   auto wave_sync = [&]() {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
   };
+  // node-sum roles: lane = (column X = lane>>2, y side dy, z side dz); lanes 0..3 also serve column 16
+  const int X = lane >> 2, dy = (lane >> 1) & 1, dz = lane & 1;
+  const int nL = hex_idx(1, dy, dz), nR = hex_idx(0, dy, dz);  // the node on the column: right nodes of X-1, left of X
 
   double2 pin[18];
   double pxc[RECT ? 1 : 3];
@@ -789,23 +802,25 @@ __global__ __launch_bounds__(64) void k_rhs_elem_elastic_oct(const Slab s, const
   for (int k = 0; k < 18; k++) pin[k] = make_double2(0.0, 0.0);
 #pragma unroll
   for (int d = 0; d < (RECT ? 1 : 3); d++) pxc[d] = 0.0;
-  auto request = [&](int64_t e0, double2 *pin, double *pxc) {  // inputs of elements e0 .. e0+7 -> registers
-    if (e0 > a.nel - 1) e0 = a.nel - 1;
-    const int xmax = (int)((a.nel - 1 - e0 < 7) ? a.nel - 1 - e0 : 7);
-    const double2 *blk = reinterpret_cast<const double2 *>(a.gp + (e0 + eoff) * a.mat_stride + 112);
+  // step (task t, layer l of its chunk, half h): elements 8h .. 8h+7 of the run -> registers (clamped, never masked)
+  auto request = [&](int64_t t, int l, int h, double2 *pin, double *pxc) {
+    if (t >= ntasks) { t = ntasks - 1; l = 0; h = 0; }
+    const uint32_t t32 = (uint32_t)t, tt = t32 / nr, r = t32 - tt * nr, ch = tt / (uint32_t)my, ey = tt - ch * (uint32_t)my;
+    const int64_t ex0 = 16 * (int64_t)r, ezr = (int64_t)ch * ZC + l;  // element layer relative to els
+    const int nx = (int)((mx - ex0 < 16) ? mx - ex0 : 16);
+    const double2 *blk =
+        reinterpret_cast<const double2 *>(a.gp + (ex0 + mx * (ey + my * ezr) + eoff) * a.mat_stride + 112);
 #pragma unroll
     for (int k = 0; k < 18; k++) {
-      const int c = 64 * k + lane, xe = c / 144, r = c - 144 * xe;
-      pin[k] = blk[(xe < xmax ? xe : xmax) * st2 + r];
+      const int c = 64 * k + lane, xe = c / 144, rr = c - 144 * xe;
+      const int xo = (8 * h + xe < nx) ? 8 * h + xe : nx - 1;
+      // streamed once: non-temporal (6.2 -> 7.0 TB/s on the bare read pattern, scripts/ubench/read_pattern.hip)
+      typedef double d2v __attribute__((ext_vector_type(2)));
+      const d2v v = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(blk) + (xo * st2 + rr));
+      pin[k] = make_double2(v.x, v.y);
     }
-#if FEMASM_EXP >= 5
-    pxc[0] = 0.0;
-    return;
-#endif
-    const uint32_t e32 = (uint32_t)(e0 + (x < xmax ? x : xmax));  // (the host keeps nel below 2^31 for this kernel)
-    const uint32_t t = e32 / (uint32_t)mx, u = t / (uint32_t)my;
-    const int64_t ex = e32 - t * (uint32_t)mx, ey = t - u * (uint32_t)my, ez = s.els + u;
-    const double *cn = a.coords + 3 * (ex + M * (ey + N * (ez - s.cks))) + cofs;
+    const int xo = (8 * h + x < nx) ? 8 * h + x : nx - 1;
+    const double *cn = a.coords + 3 * (ex0 + xo + M * (ey + N * (s.els + ezr - s.cks))) + cofs;
     pxc[0] = cn[0];
     if constexpr (!RECT) {
       pxc[1] = cn[1];
@@ -813,128 +828,161 @@ __global__ __launch_bounds__(64) void k_rhs_elem_elastic_oct(const Slab s, const
     }
   };
 
-  // The finished group leaves one step late, right after the next commit and BEFORE the next request: a wave's
-  // memory operations retire in order, so a store issued after a load makes the wait for that load wait for the
-  // store's acknowledgement as well (measured: 0.27 ms of 1.12 ms with the stores at the end of the group).
-  auto store_group = [&](int64_t gs) {
+  int64_t t = blockIdx.x;
+  request(t, 0, 0, pin, pxc);
+  for (; t < ntasks; t += gridDim.x) {
+    const uint32_t t32 = (uint32_t)t, tt = t32 / nr, r = t32 - tt * nr, ch = tt / (uint32_t)my;
+    const int nx = (int)((mx - 16 * (int64_t)r < 16) ? mx - 16 * (int64_t)r : 16);
+    const int nlz = (nlay - (int)ch * ZC < ZC) ? nlay - (int)ch * ZC : ZC;
+    double *rec = a.elemF + t * (int64_t)((ZC + 1) * 128);
+    double carry[3] = {0.0, 0.0, 0.0}, carry16[3] = {0.0, 0.0, 0.0};
+    auto emit = [&](const double *o, const double *o16, int l) {  // record of node layer l of the chunk
+      if (dz == 0) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) {  // one contiguous 3 KB block, 16 bytes per lane
-      const int idx = lane + 64 * k, t = idx >> 3, part = idx & 7;
-      *reinterpret_cast<double2 *>(a.elemF + (gs * 24 + t) * 16 + 2 * part) =
-          *reinterpret_cast<const double2 *>(&sh_out[t][2 * part]);
-    }
-  };
-  int64_t g = blockIdx.x, gprev = -1;
-  if (g < ngroups) request(16 * g, pin, pxc);
-  for (; g < ngroups; g += gridDim.x) {
-#pragma unroll 1
-    for (int half = 0; half < 2; half++) {
-      // commit the step's inputs, then ask for the next step's
-      {
-        double2 *dst = reinterpret_cast<double2 *>(sh_in);
+        for (int c = 0; c < 3; c++) sh_o[(c * 2 + dy) * 20 + X] = o[c];
+        if (lane < 4)
 #pragma unroll
-        for (int k = 0; k < 18; k++) {
-          const int c = 64 * k + lane, xe = c / 144, r = c - 144 * xe;
-          dst[xe * (S / 2) + r] = pin[k];
-        }
-        if constexpr (RECT) {
-          sh_xc[x][j] = pxc[0];
-        } else {
-#pragma unroll
-          for (int d = 0; d < 3; d++) sh_xc[x][3 * j + d] = pxc[d];
-        }
+          for (int c = 0; c < 3; c++) sh_o[(c * 2 + dy) * 20 + 16] = o16[c];
       }
-      if (half == 0 && gprev >= 0) store_group(gprev);
-      request(half == 0 ? 16 * g + 8 : 16 * (g + gridDim.x), pin, pxc);
       wave_sync();
-      const double *in = sh_in + x * S;
-#if FEMASM_EXP >= 4  // skeleton: the input stream and the output lines only
-      {
-        const double v = in[j] + in[24 + j] + sh_xc[x][j & 3];
-        wave_sync();
-#pragma unroll
-        for (int c = 0; c < 3; c++) sh_out[3 * j + c][8 * half + x] = v;
-        wave_sync();
-        continue;
-      }
+#if FEMASM_EXP == 7
+      if (sh_o[0] == 123.456)
 #endif
-      double dx, dy, dz;
-      if constexpr (RECT) {
-        const double2 cx = *reinterpret_cast<const double2 *>(&sh_xc[x][0]);
-        const double2 cy = *reinterpret_cast<const double2 *>(&sh_xc[x][2]);
-        const double2 cz = *reinterpret_cast<const double2 *>(&sh_xc[x][4]);
-        dx = fabs(cx.x - cx.y); dy = fabs(cy.x - cy.y); dz = fabs(cz.x - cz.y);
-      } else {
-        const double *xc = sh_xc[x];
-        dx = fabs(xc[0] - xc[9]); dy = fabs(xc[1] - xc[4]); dz = fabs(xc[2] - xc[14]);  // S3:560-562
+      {
+        typedef double d2v __attribute__((ext_vector_type(2)));
+        const double2 v = *reinterpret_cast<const double2 *>(&sh_o[2 * lane]);
+        d2v vv; vv.x = v.x; vv.y = v.y;
+        __builtin_nontemporal_store(vv, reinterpret_cast<d2v *>(rec + l * 128 + 2 * lane));
       }
-      double sn[3][3], u[3];
-#pragma unroll
-      for (int ax = 0; ax < 3; ax++) {  // face Gauss point p = j + 8 ax: traction sigma.n * face Jacobian, S3:568-648
-        const int p = j + 8 * ax;
-        const double pe = in[p], pn = in[24 + p];
-        const double t = pe / ((1.0 + pn) * (1.0 - 2.0 * pn));  // S3:585-593 with one division
-        const double d11 = t * (1 - pn), d12 = t * pn, d44 = t * (0.5 * (1 - 2 * pn));
-        const double *gx = in + 72 + 3 * p, *gy = in + 144 + 3 * p, *gz = in + 216 + 3 * p;
-        const double e0 = gx[0], e1 = gy[1], e2 = gz[2];
-        const double e3 = gx[1] + gy[0], e4 = gy[2] + gz[1], e5 = gx[2] + gz[0];
-        const double z0 = d11 * e0 + d12 * e1 + d12 * e2;
-        const double z1 = d12 * e0 + d11 * e1 + d12 * e2;
-        const double z2 = d12 * e0 + d12 * e1 + d11 * e2;
-        const double z3 = d44 * e3, z4 = d44 * e4, z5 = d44 * e5;
-        double Jp;
-        if (ax == 0)      { sn[ax][0] = z0 * side; sn[ax][1] = z3 * side; sn[ax][2] = z5 * side; Jp = (0.5 * dy) * (0.5 * dz); }
-        else if (ax == 1) { sn[ax][0] = z3 * side; sn[ax][1] = z1 * side; sn[ax][2] = z4 * side; Jp = (0.5 * dx) * (0.5 * dz); }
-        else              { sn[ax][0] = z5 * side; sn[ax][1] = z4 * side; sn[ax][2] = z2 * side; Jp = (0.5 * dx) * (0.5 * dy); }
-        const double fac = 1.0 * Jp;
-#pragma unroll
-        for (int c = 0; c < 3; c++) sn[ax][c] *= fac;
-      }
-      {  // volume Gauss point j: w detJ f, S3:534-545
-        double fac;
-        if constexpr (RECT) fac = 1.0 * ((0.5 * dx) * (0.5 * dy) * (0.5 * dz));
-        else fac = 1.0 * det3_only(sh_G[j], sh_xc[x]);
-        u[0] = fac * in[48 + j];
-        u[1] = fac * in[56 + j];
-        u[2] = fac * in[64 + j];
-      }
-      wave_sync();  // every lane has consumed its inputs: the region is reused for the tractions
-      double2 *w01 = reinterpret_cast<double2 *>(sh_in) + x * W01S;  // [element][32 Gauss points] (c = 0,1)
-      double *w2 = sh_in + 2 * 8 * W01S + x * W2S;                   // [element][32] (c = 2)
-#pragma unroll
-      for (int ax = 0; ax < 3; ax++) {
-        w01[j + 8 * ax] = make_double2(sn[ax][0], sn[ax][1]);
-        w2[j + 8 * ax] = sn[ax][2];
-      }
-      w01[24 + j] = make_double2(u[0], u[1]);
-      w2[24 + j] = u[2];
       wave_sync();
-      double o[3] = {0.0, 0.0, 0.0};
+    };
+#pragma unroll 1
+    for (int l = 0; l < nlz; l++) {
+#pragma unroll 1
+      for (int h = 0; h < 2; h++) {
+        {
+          double2 *dst = reinterpret_cast<double2 *>(sh_in);
 #pragma unroll
-      for (int ax = 0; ax < 3; ax++)
+          for (int k = 0; k < 18; k++) {
+            const int c = 64 * k + lane, xe = c / 144, rr = c - 144 * xe;
+            dst[xe * (S / 2) + rr] = pin[k];
+          }
+          if constexpr (RECT) {
+            sh_xc[x][j] = pxc[0];
+          } else {
 #pragma unroll
-        for (int m = 0; m < 4; m++) {
-          const double2 v = w01[pb[ax] + m];
-          const double v2 = w2[pb[ax] + m];
-          o[0] = fma(cff[ax][m], v.x, o[0]);
-          o[1] = fma(cff[ax][m], v.y, o[1]);
-          o[2] = fma(cff[ax][m], v2, o[2]);
+            for (int d = 0; d < 3; d++) sh_xc[x][3 * j + d] = pxc[d];
+          }
+        }
+        {  // the step after this one
+          int64_t tn = t;
+          int ln = l, hn = h + 1;
+          if (hn == 2) { hn = 0; ln = l + 1; }
+          if (ln == nlz) { ln = 0; tn = t + gridDim.x; }
+          request(tn, ln, hn, pin, pxc);
+        }
+        wave_sync();
+        const double *in = sh_in + x * S;
+        double dx, dyy, dzz;
+        if constexpr (RECT) {
+          const double2 cx = *reinterpret_cast<const double2 *>(&sh_xc[x][0]);
+          const double2 cy = *reinterpret_cast<const double2 *>(&sh_xc[x][2]);
+          const double2 cz = *reinterpret_cast<const double2 *>(&sh_xc[x][4]);
+          dx = fabs(cx.x - cx.y); dyy = fabs(cy.x - cy.y); dzz = fabs(cz.x - cz.y);
+        } else {
+          const double *xc = sh_xc[x];
+          dx = fabs(xc[0] - xc[9]); dyy = fabs(xc[1] - xc[4]); dzz = fabs(xc[2] - xc[14]);  // S3:560-562
+        }
+        double sn[3][3], u[3];
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) {  // face Gauss point p = j + 8 ax: traction sigma.n * face Jacobian, S3:568-648
+          const int p = j + 8 * ax;
+          const double pe = in[p], pn = in[24 + p];
+          const double tq = pe / ((1.0 + pn) * (1.0 - 2.0 * pn));  // S3:585-593 with one division
+          const double d11 = tq * (1 - pn), d12 = tq * pn, d44 = tq * (0.5 * (1 - 2 * pn));
+          const double *gx = in + 72 + 3 * p, *gy = in + 144 + 3 * p, *gz = in + 216 + 3 * p;
+          const double e0 = gx[0], e1 = gy[1], e2 = gz[2];
+          const double e3 = gx[1] + gy[0], e4 = gy[2] + gz[1], e5 = gx[2] + gz[0];
+          const double z0 = d11 * e0 + d12 * e1 + d12 * e2;
+          const double z1 = d12 * e0 + d11 * e1 + d12 * e2;
+          const double z2 = d12 * e0 + d12 * e1 + d11 * e2;
+          const double z3 = d44 * e3, z4 = d44 * e4, z5 = d44 * e5;
+          double Jp;
+          if (ax == 0)      { sn[ax][0] = z0 * side; sn[ax][1] = z3 * side; sn[ax][2] = z5 * side; Jp = (0.5 * dyy) * (0.5 * dzz); }
+          else if (ax == 1) { sn[ax][0] = z3 * side; sn[ax][1] = z1 * side; sn[ax][2] = z4 * side; Jp = (0.5 * dx) * (0.5 * dzz); }
+          else              { sn[ax][0] = z5 * side; sn[ax][1] = z4 * side; sn[ax][2] = z2 * side; Jp = (0.5 * dx) * (0.5 * dyy); }
+          const double fac = 1.0 * Jp;
+#pragma unroll
+          for (int c = 0; c < 3; c++) sn[ax][c] *= fac;
+        }
+        {  // volume Gauss point j: w detJ f, S3:534-545
+          double fac;
+          if constexpr (RECT) fac = 1.0 * ((0.5 * dx) * (0.5 * dyy) * (0.5 * dzz));
+          else fac = 1.0 * det3_only(sh_G[j], sh_xc[x]);
+          u[0] = fac * in[48 + j];
+          u[1] = fac * in[56 + j];
+          u[2] = fac * in[64 + j];
+        }
+        wave_sync();  // every lane has consumed its inputs: the region is reused for the tractions
+        double2 *w01 = reinterpret_cast<double2 *>(sh_in) + x * W01S;
+        double *w2 = sh_in + 2 * 8 * W01S + x * W2S;
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) {
+          w01[j + 8 * ax] = make_double2(sn[ax][0], sn[ax][1]);
+          w2[j + 8 * ax] = sn[ax][2];
+        }
+        w01[24 + j] = make_double2(u[0], u[1]);
+        w2[24 + j] = u[2];
+        wave_sync();
+        double o[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++)
+#pragma unroll
+          for (int m = 0; m < 4; m++) {
+            const double2 v = w01[pb[ax] + m];
+            const double v2 = w2[pb[ax] + m];
+            o[0] = fma(cff[ax][m], v.x, o[0]);
+            o[1] = fma(cff[ax][m], v.y, o[1]);
+            o[2] = fma(cff[ax][m], v2, o[2]);
+          }
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          const double2 v = w01[24 + m];
+          const double v2 = w2[24 + m];
+          o[0] = fma(cfv[m], v.x, o[0]);
+          o[1] = fma(cfv[m], v.y, o[1]);
+          o[2] = fma(cfv[m], v2, o[2]);
         }
 #pragma unroll
-      for (int m = 0; m < 8; m++) {
-        const double2 v = w01[24 + m];
-        const double v2 = w2[24 + m];
-        o[0] = fma(cfv[m], v.x, o[0]);
-        o[1] = fma(cfv[m], v.y, o[1]);
-        o[2] = fma(cfv[m], v2, o[2]);
+        for (int c = 0; c < 3; c++) sh_o[((8 * h + x) * 8 + j) * 3 + c] = o[c];  // node j of element 8h + x of the run
+        wave_sync();
       }
+      // node columns of the run on this element layer: right nodes of element X-1 + left nodes of element X
+      double v[3], v16[3];
 #pragma unroll
-      for (int c = 0; c < 3; c++) sh_out[3 * j + c][8 * half + x] = o[c];
-      wave_sync();  // sh_in is rewritten by the next step's commit
+      for (int c = 0; c < 3; c++) {
+        const double left = (X > 0 && X - 1 < nx) ? sh_o[((X - 1) * 8 + nL) * 3 + c] : 0.0;
+        const double right = (X < nx) ? sh_o[(X * 8 + nR) * 3 + c] : 0.0;
+        v[c] = left + right;
+        v16[c] = (lane < 4 && nx == 16) ? sh_o[(15 * 8 + nL) * 3 + c] : 0.0;
+      }
+      wave_sync();  // sh_o is reused for the record
+      // node layer l of the chunk: upper nodes of element layer l-1 (carried) + lower nodes of layer l
+      double o[3], o16[3];
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        o[c] = carry[c] + v[c];
+        o16[c] = carry16[c] + v16[c];
+      }
+      emit(o, o16, l);
+#pragma unroll
+      for (int c = 0; c < 3; c++) {  // the z-lower lanes receive their partner's upper-node sums
+        carry[c] = __shfl_xor(v[c], 1);
+        carry16[c] = __shfl_xor(v16[c], 1);
+      }
     }
-    gprev = g;
+    emit(carry, carry16, nlz);  // the node layer above the chunk's last element layer
   }
-  if (gprev >= 0) store_group(gprev);
 }
 
 // ---------------------------------------------------------------------------
@@ -1054,7 +1102,7 @@ __global__ __launch_bounds__(256) void k_op_elem(const Slab s, const RArgs a, do
 // RHS, pass 2: one thread per node; contributions added in the reference's element
 // order (k -> j -> i) (S3: Fe + Ge of an element enter as one term); then the Dirichlet value.
 // ---------------------------------------------------------------------------
-template <int KIND>
+template <int KIND, bool RUNS = false>
 __global__ __launch_bounds__(256) void k_rhs_gather(const Slab s, const RArgs a) {
   using T = Traits<KIND>;
   constexpr int NSD = T::NSD, DOF = T::DOF, NFE = T::NFE;
@@ -1071,7 +1119,31 @@ __global__ __launch_bounds__(256) void k_rhs_gather(const Slab s, const RArgs a)
 #pragma unroll
   for (int c = 0; c < DOF; c++) b[c] = 0.0;
 
-  if constexpr (NSD == 3) {
+  if constexpr (RUNS) {
+    // records of k_rhs_elem_elastic_runs: element layer k-1 before k, row j-1 before j, run r-1 before r
+    constexpr int ZC = RUNS_ZC;
+    const int64_t nlay = s.ele - s.els, nr = (mx + 15) >> 4, nzc = (nlay + ZC - 1) / ZC;
+    const int64_t qz = k - s.els, c0 = qz / ZC, l0 = qz - c0 * ZC;
+    const int64_t r0 = i >> 4, X0 = i & 15;
+#pragma unroll
+    for (int pz = 0; pz < 2; pz++) {
+      const int64_t ch = pz == 0 ? c0 - 1 : c0, l = pz == 0 ? ZC : l0;
+      if (pz == 0 ? !(l0 == 0 && c0 > 0) : !(c0 < nzc)) continue;
+#pragma unroll
+      for (int py = 0; py < 2; py++) {
+        const int64_t ey = j - 1 + py;  // py = 0: the row below the node (its dy = 1 side)
+        if (ey < 0 || ey >= my) continue;
+#pragma unroll
+        for (int px = 0; px < 2; px++) {
+          const int64_t r = px == 0 ? r0 - 1 : r0, Xv = px == 0 ? 16 : X0;
+          if (px == 0 ? !(X0 == 0 && r0 > 0) : !(r0 < nr)) continue;
+          const double *R = a.elemF + (((ch * my + ey) * nr + r) * (ZC + 1) + l) * 128 + (1 - py) * 20 + Xv;
+#pragma unroll
+          for (int c = 0; c < DOF; c++) b[c] = b[c] + R[c * 40];
+        }
+      }
+    }
+  } else if constexpr (NSD == 3) {
     const int64_t e111 = i + mx * (j + my * (k - s.els));  // element (i,j,k); the others by constant offsets
 #pragma unroll
     for (int oz = -1; oz <= 0; oz++)

@@ -39,12 +39,22 @@ __global__ __launch_bounds__(256) void coop(const double *gp, int64_t nel, doubl
   const int qk4 = (q + 128 < 144) ? q + 128 : 143;
   double2 acc = make_double2(0, 0);
   double2 pins[2][5];
+  typedef double d2v __attribute__((ext_vector_type(2)));
   auto req = [&](int64_t e, double2 *pin) {
     if (e >= nel) e = nel - 1;
     const double2 *src = reinterpret_cast<const double2 *>(gp + e * 400 + 112);
+    if (wmode >= 10) {  // non-temporal loads
+      const d2v *sv = reinterpret_cast<const d2v *>(src);
 #pragma unroll
-    for (int k = 0; k < 4; k++) pin[k] = src[q + 32 * k];
-    pin[4] = src[qk4];
+      for (int k = 0; k < 5; k++) {
+        const d2v v = __builtin_nontemporal_load(&sv[k < 4 ? q + 32 * k : qk4]);
+        pin[k] = make_double2(v.x, v.y);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) pin[k] = src[q + 32 * k];
+      pin[4] = src[qk4];
+    }
   };
   const int64_t ngroups = nel / 16;
   if (MODE == 0) {
@@ -63,7 +73,7 @@ __global__ __launch_bounds__(256) void coop(const double *gp, int64_t nel, doubl
           const int64_t en = (it < 6) ? 16 * g + 2 * (it + 2) : 16 * (g + gstride) + 2 * (it - 6);
           req(en + el, pins[h]);
           if (out && it == 7) {  // the element vectors of the group: 3 KB
-            if (wmode == 0) {      // one contiguous block per group
+            if (wmode == 0 || wmode == 10) {      // one contiguous block per group
 #pragma unroll
               for (int k = 0; k < 3; k++) *reinterpret_cast<double2 *>(out + g * 384 + (lane + 64 * k) * 2) = acc;
             } else if (wmode == 2) {  // contiguous block, non-temporal
@@ -72,6 +82,16 @@ __global__ __launch_bounds__(256) void coop(const double *gp, int64_t nel, doubl
                 double *o = out + g * 384 + (lane + 64 * k) * 2;
                 __builtin_nontemporal_store(acc.x, o);
                 __builtin_nontemporal_store(acc.y, o + 1);
+              }
+            } else if (wmode >= 20 && wmode <= 23) {  // contiguous block, NT loads, store cache-policy bits
+#pragma unroll
+              for (int k = 0; k < 3; k++) {
+                double *o = out + g * 384 + (lane + 64 * k) * 2;
+                d2v av; av.x = acc.x; av.y = acc.y;
+                if (wmode == 20) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(o), "v"(av) : "memory");
+                if (wmode == 21) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(o), "v"(av) : "memory");
+                if (wmode == 22) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(o), "v"(av) : "memory");
+                if (wmode == 23) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(o), "v"(av) : "memory");
               }
             } else if (wmode == 3) {  // contiguous block, only every 4th group writes 4x the data (same bytes, burstier)
               if ((g / gstride) % 4 == 3)
@@ -104,6 +124,13 @@ __global__ __launch_bounds__(256) void coop(const double *gp, int64_t nel, doubl
         }
   }
   if (acc.x == 123.456) sink[0] = acc.y;
+}
+__global__ __launch_bounds__(256) void wr_only(double *out, int64_t ngroups) {
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double2 acc = make_double2(1.0, 2.0);
+  for (int64_t g = (int64_t)blockIdx.x * 4 + w; g < ngroups; g += (int64_t)gridDim.x * 4)
+#pragma unroll
+    for (int k = 0; k < 3; k++) *reinterpret_cast<double2 *>(out + g * 384 + (lane + 64 * k) * 2) = acc;
 }
 // plain linear read
 __global__ void lin(const double2 *p, int64_t n2, double *sink) {
@@ -139,6 +166,13 @@ int main() {
     timeit("coop traversal + 3 KB block stores per group", b288, [&] { coop<0><<<256 * wg, 256>>>(gp, nel, sink, outb, 0); });
     timeit("coop traversal + block stores, non-temporal", b288, [&] { coop<0><<<256 * wg, 256>>>(gp, nel, sink, outb, 2); });
     timeit("coop traversal + 12 KB stores every 4th group", b288, [&] { coop<0><<<256 * wg, 256>>>(gp, nel, sink, outb, 3); });
+    timeit("coop traversal, NT loads, no stores", b288, [&] { coop<0><<<256 * wg, 256>>>(gp, nel, sink, nullptr, 10); });
+    timeit("coop traversal, NT loads + block stores", b288, [&] { coop<0><<<256 * wg, 256>>>(gp, nel, sink, outb, 10); });
+    timeit("block stores only (bytes = 192/el)", nel * 192.0, [&] { wr_only<<<256 * wg, 256>>>(outb, nel / 16); });
+    timeit("NT loads + stores sc0 sc1", b288, [&] { coop<0><<<256 * wg, 256>>>(gp, nel, sink, outb, 20); });
+    timeit("NT loads + stores sc1", b288, [&] { coop<0><<<256 * wg, 256>>>(gp, nel, sink, outb, 21); });
+    timeit("NT loads + stores sc0 sc1 nt", b288, [&] { coop<0><<<256 * wg, 256>>>(gp, nel, sink, outb, 22); });
+    timeit("NT loads + stores nt", b288, [&] { coop<0><<<256 * wg, 256>>>(gp, nel, sink, outb, 23); });
     timeit("coop traversal + component-major stores", b288, [&] { coop<0><<<256 * wg, 256>>>(gp, nel, sink, outb, 1); });
     timeit("coop traversal, workgroup-owned 64, 8 consecutive/step", b288, [&] { coop<1><<<256 * wg, 256>>>(gp, nel, sink); });
     timeit("records [0,400) whole, 2 ahead (bytes=400)", b400, [&] { rd<2><<<256 * wg, 256>>>(gp, nel, sink, 0); });

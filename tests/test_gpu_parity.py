@@ -95,6 +95,7 @@ CASES = [
     ("p3", (5, 5, 5)), ("p3", (9, 6, 7)), ("p3", (2, 2, 2)), ("p3", (3, 2, 10)), ("p3", (17, 13, 6)),
     ("e2", (2, 2)), ("e2", (9, 7)), ("e2", (40, 21)), ("e2", (17, 5)), ("e2", (3, 50)),
     ("s3", (2, 2, 2)), ("s3", (4, 4, 4)), ("s3", (8, 6, 7)), ("s3", (5, 9, 3)), ("s3", (13, 4, 6)),
+    ("s3", (38, 5, 36)),
 ]
 
 
@@ -193,8 +194,12 @@ def test_compressed_bc_rows_match_petsc_matzerorows_default(env, kind, dims):
     plan.close()
 
 
+# the last three: shapes of the S3 RHS runs kernel -- rows that are not a multiple of 16 elements (short last run,
+# node column on a run boundary), more than one chunk of 32 element layers (node layers whose halves come from two
+# chunks), slabs whose first element layer is owed to the rank below
 @pytest.mark.parametrize("kind,dims,nslab", [("p3", (5, 4, 9), 3), ("e2", (9, 11), 2), ("s3", (4, 5, 8), 2),
-                                             ("s3", (3, 3, 7), 4)])
+                                             ("s3", (3, 3, 7), 4), ("s3", (38, 4, 36), 2), ("s3", (18, 3, 70), 3),
+                                             ("s3", (50, 3, 5), 2)])
 @pytest.mark.parametrize("split", [False, True])
 def test_slabs_plus_interface_exchange_equal_the_global_system(env, kind, dims, nslab, split):
     """Multi-GPU path on one device: one plan per slab, the send buffer of slab r+1 handed to slab r
