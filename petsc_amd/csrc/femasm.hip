@@ -960,7 +960,7 @@ int femasm_interface_apply(femasm_plan *p, const femasm_bc *bcs, double *csr_val
     return fail(FEMASM_ERR_ARG, "femasm_interface_apply needs device-resident csr_values / b");
   const int bc = bcs ? bcs->kind : FEMASM_BC_NONE;
   const int64_t plane = (p->s.nsd == 3) ? p->s.dim[0] * p->s.dim[1] : p->s.dim[0];
-  hipLaunchKernelGGL(k_iface_apply, dim3(nblk(plane * p->s.dof)), dim3(256), 0, p->stream, p->s, bc, csr_values, b,
+  hipLaunchKernelGGL(k_iface_apply, dim3(nblk(plane, 4)), dim3(256), 0, p->stream, p->s, bc, csr_values, b,
                      p->recv, p->recv + p->recv_nnz);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(p->stream));

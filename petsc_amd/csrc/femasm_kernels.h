@@ -1204,29 +1204,29 @@ __global__ __launch_bounds__(256) void k_rhs_gather(const Slab s, const RArgs a)
 }
 
 // ---------------------------------------------------------------------------
-// interface apply: own + received, one thread per row of the top owned node layer
+// interface apply: own + received on the top owned node layer; one wave per node (its dof rows are one
+// contiguous range of the CSR array, read and written coalesced), Dirichlet nodes skipped
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_iface_apply(const Slab s, int bc, double *vals, double *b,
                                                      const double *recvK, const double *recvB) {
   const int64_t M = s.dim[0], N = s.dim[1];
   const int64_t layer = s.ke - 1;
   const int64_t nnode = (s.nsd == 3) ? M * N : M;
-  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (r >= nnode * s.dof) return;
-  const int c = (int)(r % s.dof);
-  const int64_t q = r / s.dof;
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (q >= nnode) return;
   int64_t i = q % M, j, k;
   if (s.nsd == 3) { j = q / M; k = layer; } else { j = layer; k = 0; }
   if (bc != BC_POISSON && is_bc_node(s, bc, i, j, k)) return;
-  const int64_t cnt = (int64_t)span1(i, s.dim[0]) * span1(j, s.dim[1]) * span1(k, s.dim[2]) * s.dof;
-  const int64_t rs = row_start(s, i, j, k, c);
+  const int64_t cnt = (int64_t)span1(i, s.dim[0]) * span1(j, s.dim[1]) * span1(k, s.dim[2]) * s.dof * s.dof;
+  const int64_t rs = row_start(s, i, j, k, 0);
   const int64_t i0 = 0, j0 = (s.nsd == 3) ? 0 : layer, k0 = (s.nsd == 3) ? layer : 0;
   const int64_t rs_recv = rs - row_start(s, i0, j0, k0, 0);
   if (vals && recvK)
-    for (int64_t t = 0; t < cnt; t++) vals[rs + t] = vals[rs + t] + recvK[rs_recv + t];
-  if (b && recvB) {
-    const int64_t lr = (q + nnode * (layer - s.ks)) * s.dof + c;
-    b[lr] = b[lr] + recvB[q * s.dof + c];
+    for (int64_t t = lane; t < cnt; t += 64) vals[rs + t] = vals[rs + t] + recvK[rs_recv + t];
+  if (b && recvB && lane < s.dof) {
+    const int64_t lr = (q + nnode * (layer - s.ks)) * s.dof + lane;
+    b[lr] = b[lr] + recvB[q * s.dof + lane];
   }
 }
 
