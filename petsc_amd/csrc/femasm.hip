@@ -75,6 +75,7 @@ struct femasm_plan {
   double *elemF = nullptr;
   int64_t nelp = 0;                    // nel rounded up to whole blocks of 16 elements
   int64_t elemF_count = 0;             // doubles allocated in elemF
+  double *lines = nullptr;             // P3 RHS on a rectilinear mesh: the three 1-D factor lines
   // interface buffers (K rows of one node layer in CSR layout, then the b slice)
   double *send = nullptr, *recv = nullptr;
   int64_t send_count = 0, recv_count = 0, send_nnz = 0, recv_nnz = 0;
@@ -303,6 +304,16 @@ int launch_rhs(femasm_plan *p, const femasm_material *mat, int bc, double *out, 
   const bool runs = KIND == KIND_ELASTIC && a.gp && (a.mat_stride & 1) == 0 && ((uintptr_t)a.gp & 15) == 0 &&
                     ntasks < ((int64_t)1 << 31) && ntasks * (RUNS_ZC + 1) * 128 <= p->elemF_count;
   a.runs = runs ? 1 : 0;
+  if (KIND == KIND_POISSON && a.rect) {
+    // rectilinear mesh (verdict of the pre-pass read on the device): b as an outer product of three lines; the
+    // element pass and the gather below then return at once
+    const int64_t nl = p->s.dim[0] + p->s.dim[1] + (p->cke - p->s.cks);
+    if (!p->lines) HIPCHK(hipMalloc(&p->lines, (size_t)nl * sizeof(double)));
+    hipLaunchKernelGGL(k_poisson_rhs_lines, dim3(nblk(nl)), dim3(256), 0, p->stream, sl, a, p->lines);
+    const dim3 g3(nblk(p->s.dim[0]), (unsigned)p->s.dim[1], (unsigned)(s1 - s0));
+    hipLaunchKernelGGL(k_poisson_rhs_rect, g3, dim3(256), 0, p->stream, sl, a, p->lines);
+    HIPCHK(hipGetLastError());
+  }
   if (do_elem && nel > 0) {
     if (runs) {
       // persistent one-wave workgroups: one resident set
@@ -478,7 +489,7 @@ int femasm_plan_destroy(femasm_plan *p) {
   }
 #endif
   void *bufs[] = {p->coords_dev, p->rowptr, p->colidx, p->elemF, p->own_send ? p->send : nullptr,
-                  p->own_recv ? p->recv : nullptr, p->bad, p->stage_vals, p->stage_b, p->stage_gp};
+                  p->own_recv ? p->recv : nullptr, p->bad, p->stage_vals, p->stage_b, p->stage_gp, p->lines};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   for (auto &e : p->ev)

@@ -602,6 +602,9 @@ __global__ __launch_bounds__(256) void k_rhs_elem(const Slab s, const RArgs a) {
   constexpr int NFE = T::NFE;
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= a.nel) return;
+  if constexpr (KIND == KIND_POISSON) {
+    if (a.rect != 0 && a.bad[3] == 0ULL) return;  // rectilinear mesh: k_poisson_rhs_rect has written b
+  }
   const int64_t M = s.dim[0], N = s.dim[1];
   const int64_t mx = M - 1, my = N - 1;
   double F[NFE];
@@ -1111,6 +1114,9 @@ __global__ __launch_bounds__(256) void k_rhs_gather(const Slab s, const RArgs a)
   // grid = (ceil(M/256), N or layers, layers or 1): no integer division
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= M) return;
+  if constexpr (KIND == KIND_POISSON) {
+    if (a.rect != 0 && a.bad[3] == 0ULL) return;  // rectilinear mesh: k_poisson_rhs_rect has written b
+  }
   int64_t j, k, q;
   if constexpr (NSD == 3) { j = blockIdx.y; k = a.s0 + blockIdx.z; q = i + M * (j + N * (int64_t)blockIdx.z); }
   else                    { j = a.s0 + blockIdx.y; k = 0; q = i + M * (int64_t)blockIdx.y; }
@@ -1201,6 +1207,57 @@ __global__ __launch_bounds__(256) void k_rhs_gather(const Slab s, const RArgs a)
   }
 #pragma unroll
   for (int c = 0; c < DOF; c++) a.out[q * DOF + c] = b[c];
+}
+
+// ---------------------------------------------------------------------------
+// P3 right-hand side on a rectilinear mesh (verified by k_check_rectilinear earlier on this stream, verdict in
+// bad[3]; otherwise both kernels return at once and k_rhs_elem + k_rhs_gather do the work).  Every element is a box,
+// so det J = (hx/2)(hy/2)(hz/2), a Gauss point's position and the trilinear N_a factor per axis, and so does
+// f = 3 pi^2 sin(pi x) sin(pi y) sin(pi z) (P3:352-359): the assembled entry of node (i,j,k) is
+// 3 pi^2 Sx(i) Sy(j) Sz(k) with S(n) = sum over the two elements either side of n and their two Gauss abscissae
+// of (h/2) N_side(xi) sin(pi x(xi)) -- the same terms as P3:534-567 + the node sum, in another order (rounding only).
+// Pass 1: the three lines of S (z restricted to the element layers this rank assembles); pass 2: the outer product,
+// Dirichlet nodes 0 (P3:624-630).  b is written once, no element vectors: 0.34 + 0.40 ms -> 0.05 ms at 256^3.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_poisson_rhs_lines(const Slab s, const RArgs a, double *lines) {
+  if (!(a.rect != 0 && a.bad[3] == 0ULL)) return;
+  const int64_t M = s.dim[0], N = s.dim[1], L = a.cke - s.cks;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= M + N + L) return;
+  int64_t n, cnt, stride, e0, e1;  // node index on its line, nodes on the line, coordinate stride, element range
+  int comp;
+  if (t < M)          { n = t;         cnt = M; stride = 3;         comp = 0; e0 = 0; e1 = M - 1; }
+  else if (t < M + N) { n = t - M;     cnt = N; stride = 3 * M;     comp = 1; e0 = 0; e1 = N - 1; }
+  else                { n = t - M - N; cnt = L; stride = 3 * M * N; comp = 2; e0 = s.els - s.cks; e1 = s.ele - s.cks; }
+  (void)cnt;
+  double S = 0.0;
+#pragma unroll
+  for (int side = 1; side >= 0; side--) {  // element n-1 (the node is its upper end: side 1), then element n
+    const int64_t e = n - side;
+    if (e < e0 || e >= e1) continue;
+    const double lo = a.coords[stride * e + comp], hi = a.coords[stride * (e + 1) + comp];
+    const double hh = 0.5 * (hi - lo);
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+      const double xi = (p == 0) ? -GAUSS_G : GAUSS_G;
+      const double Nlo = 0.5 * (1.0 - xi), Nhi = 0.5 * (1.0 + xi);
+      const double pos = Nlo * lo + Nhi * hi;
+      S += hh * (side ? Nhi : Nlo) * sinpi(pos);
+    }
+  }
+  lines[t] = S;
+}
+__global__ __launch_bounds__(256) void k_poisson_rhs_rect(const Slab s, const RArgs a, const double *lines) {
+  if (!(a.rect != 0 && a.bad[3] == 0ULL)) return;
+  constexpr double PI = 3.14159265358979323846264338327950288;
+  const int64_t M = s.dim[0], N = s.dim[1];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M) return;
+  const int64_t j = blockIdx.y, k = a.s0 + blockIdx.z;
+  const int64_t q = i + M * (j + N * (int64_t)blockIdx.z);
+  double v = 0.0;
+  if (!is_bc_node(s, a.bc, i, j, k)) v = 3.0 * PI * PI * lines[i] * lines[M + j] * lines[M + N + (k - s.cks)];
+  a.out[q] = v;
 }
 
 // ---------------------------------------------------------------------------

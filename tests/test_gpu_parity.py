@@ -200,13 +200,14 @@ def test_compressed_bc_rows_match_petsc_matzerorows_default(env, kind, dims):
 @pytest.mark.parametrize("kind,dims,nslab", [("p3", (5, 4, 9), 3), ("e2", (9, 11), 2), ("s3", (4, 5, 8), 2),
                                              ("s3", (3, 3, 7), 4), ("s3", (38, 4, 36), 2), ("s3", (18, 3, 70), 3),
                                              ("s3", (50, 3, 5), 2)])
-@pytest.mark.parametrize("split", [False, True])
-def test_slabs_plus_interface_exchange_equal_the_global_system(env, kind, dims, nslab, split):
+@pytest.mark.parametrize("split,perturb", [(False, True), (True, True), (True, False)])
+def test_slabs_plus_interface_exchange_equal_the_global_system(env, kind, dims, nslab, split, perturb):
     """Multi-GPU path on one device: one plan per slab, the send buffer of slab r+1 handed to slab r
     (what RCCL does in bench.py), then femasm_interface_apply.  split: the send buffer is produced by
     femasm_assemble_interface ahead of the full call (the overlap path of bench.py --gpus N)."""
     torch, F, dev, slab = env["torch"], env["F"], env["dev"], env["slab"]
-    case = make_case(env, kind, dims, vary_material=(kind != "p3"))
+    # perturb=False: rectilinear mesh, i.e. the level-2 kernels and the separable P3 right-hand side on slabs
+    case = make_case(env, kind, dims, perturb=perturb, vary_material=(kind != "p3" and perturb))
     M, N, P = case["dims"]
     nsd = 2 if kind == "e2" else 3
     SL = P if nsd == 3 else N
