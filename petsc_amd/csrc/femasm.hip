@@ -231,9 +231,15 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
         KArgs az = a;
         az.zc = (int32_t)zc;
         az.rect = rect ? 1 : 0;
-        dim3 grid((unsigned)((b.x1 - b.x0 + TX - 1) / TX), (unsigned)((b.y1 - b.y0 + TY - 1) / TY),
-                  (unsigned)((z1 - z0 + zc - 1) / zc));
-        hipLaunchKernelGGL(k_assemble_rowsweep<KIND>, grid, dim3(64 * (3 + RowSweep<KIND>::NRW)), 0, p->stream, p->s, az);
+        if (KIND == KIND_POISSON && rect) {  // dof 1 on a rectilinear mesh: autonomous waves, one tile row each
+          dim3 grid((unsigned)((b.x1 - b.x0 + P3W_TX - 1) / P3W_TX), (unsigned)(b.y1 - b.y0),
+                    (unsigned)((z1 - z0 + zc - 1) / zc));
+          hipLaunchKernelGGL(k_assemble_p3_rect, grid, dim3(64), 0, p->stream, p->s, az);
+        } else {
+          dim3 grid((unsigned)((b.x1 - b.x0 + TX - 1) / TX), (unsigned)((b.y1 - b.y0 + TY - 1) / TY),
+                    (unsigned)((z1 - z0 + zc - 1) / zc));
+          hipLaunchKernelGGL(k_assemble_rowsweep<KIND>, grid, dim3(64 * (3 + RowSweep<KIND>::NRW)), 0, p->stream, p->s, az);
+        }
         p->used_fast = true;
       } else {
         dim3 grid((unsigned)((b.x1 - b.x0 + SW_TX - 1) / SW_TX), (unsigned)((b.y1 - b.y0 + SW_TY - 1) / SW_TY),

@@ -886,6 +886,121 @@ __global__ __launch_bounds__(64 * (3 + RowSweep<KIND>::NRW), 2) void k_assemble_
 }
 
 // ---------------------------------------------------------------------------
+// P3 on a verified rectilinear mesh (level 2): one autonomous wave per workgroup, no record wave, no barrier.
+// For dof 1 a tile row of 64 x-consecutive interior nodes is a contiguous 13.8 KB run of the CSR array that ONE
+// wave can own: lane = node, 27 accumulators = its whole row; deposit into a wave-private stage in HBM order (all
+// 64 lanes at once), then 16 B per lane from the 128-byte boundary below the run, as in k_assemble_rowsweep --
+// but nothing to hand-shake.  The element records are three numbers (C = detJ diag(1/J_ii^2)) that follow from the
+// three coordinate lines, so every lane derives those of its eight elements itself: per step one new element
+// layer (4 elements, 4 divisions), the previous layer's kept in registers.  Same operations in the same order as
+// the record path of k_assemble_rowsweep<POISSON> (the zero off-diagonal terms dropped): same bits.
+// The premise is the rectilinearity pre-pass (bad[1]); on failure the host reassembles at level 1.
+// ---------------------------------------------------------------------------
+constexpr int P3W_TX = 64;
+__global__ __launch_bounds__(64) void k_assemble_p3_rect(const Slab s, const KArgs a) {
+  constexpr int ROW = 27, RUN = P3W_TX * ROW;
+  __shared__ double sh_stage[RUN];
+  const int lane = threadIdx.x;
+  const int64_t M = s.dim[0], N = s.dim[1];
+  const int64_t i0 = a.x0 + (int64_t)blockIdx.x * P3W_TX, j = a.y0 + blockIdx.y;
+  const int64_t zc0 = a.s0 + (int64_t)blockIdx.z * a.zc;
+  const int64_t zc1 = (zc0 + a.zc < a.s1) ? zc0 + a.zc : a.s1;
+  const int nz = (int)(zc1 - zc0);
+  const int nvx = (a.x1 - i0 < P3W_TX) ? (int)(a.x1 - i0) : P3W_TX;  // valid nodes of the run
+  const int64_t i = (lane < nvx) ? i0 + lane : i0 + nvx - 1;          // idle lanes repeat the last node
+  // half edges of the elements either side of the node, per axis: [0] = element index-1, [1] = element index
+  const double xm = a.coords[3 * (i - 1)], xc = a.coords[3 * i], xp = a.coords[3 * (i + 1)];
+  const double ym = a.coords[3 * (M * (j - 1)) + 1], yc = a.coords[3 * (M * j) + 1], yp = a.coords[3 * (M * (j + 1)) + 1];
+  const double Jx[2] = {0.5 * (xc - xm), 0.5 * (xp - xc)}, Jy[2] = {0.5 * (yc - ym), 0.5 * (yp - yc)};
+  auto zline = [&](int64_t k) { return a.coords[3 * (M * N * (k - s.cks)) + 2]; };
+  // C of the four elements (oy, ox) of element layer L; zero outside the layers this rank assembles
+  auto layer = [&](int64_t L, double (*C)[3]) {
+    const bool ok = L >= s.els && L < s.ele;
+    const double Jz = ok ? 0.5 * (zline(L + 1) - zline(L)) : 1.0;
+#pragma unroll
+    for (int oy = 0; oy < 2; oy++)
+#pragma unroll
+      for (int ox = 0; ox < 2; ox++) {
+        const double J0 = Jx[ox], J1 = Jy[oy], J2 = Jz;
+        const double wJ = 1.0 * (J0 * J1 * J2);
+        if (ok && !(wJ > 0.0)) atomicAdd(a.bad, 1ULL);
+        const double t17 = 1.0 / (J0 * J1 * J2);
+        const double q0 = (J1 * J2) * t17, q1 = (J0 * J2) * t17, q2 = (J0 * J1) * t17;
+        C[2 * oy + ox][0] = ok ? (q0 * q0) * wJ : 0.0;
+        C[2 * oy + ox][1] = ok ? (q1 * q1) * wJ : 0.0;
+        C[2 * oy + ox][2] = ok ? (q2 * q2) * wJ : 0.0;
+      }
+  };
+  double Clo[4][3], Chi[4][3];
+  layer(zc0 - 1, Clo);
+  for (int st = 0; st < nz; st++) {
+    const int64_t kn = zc0 + st;
+    layer(kn, Chi);
+    double acc[ROW];
+#pragma unroll
+    for (int q = 0; q < ROW; q++) acc[q] = 0.0;
+#pragma unroll
+    for (int as = 1; as >= 0; as--)  // element layer kn-1 (the node is on its top face), then kn
+#pragma unroll
+      for (int oy = -1; oy <= 0; oy++)
+#pragma unroll
+        for (int ox = -1; ox <= 0; ox++) {
+          const double *C = as ? Clo[2 * (oy + 1) + (ox + 1)] : Chi[2 * (oy + 1) + (ox + 1)];
+          const int ia = hex_idx(-ox, -oy, as);
+#pragma unroll
+          for (int bz = 0; bz <= 1; bz++)
+#pragma unroll
+            for (int by = 0; by <= 1; by++)
+#pragma unroll
+              for (int bx = 0; bx <= 1; bx++) {
+                const double(*R)[3] = d_refR.R[ia][hex_idx(bx, by, bz)];
+                const int t = ((bz - as + 1) * 3 + (oy + by + 1)) * 3 + (ox + bx + 1);
+                double v = acc[t];
+                v = fma(R[0][0], C[0], v);
+                v = fma(R[1][1], C[1], v);
+                v = fma(R[2][2], C[2], v);
+                acc[t] = v;
+              }
+        }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int d = 0; d < 3; d++) Clo[q][d] = Chi[q][d];
+    // deposit the row in HBM order, then write the run from the 128-byte boundary below its start
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();  // the previous step's reads of the stage are done
+    {
+      double *dst = sh_stage + lane * ROW;
+#pragma unroll
+      for (int q = 0; q < ROW; q++) dst[q] = acc[q];
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const int n = nvx * ROW;
+    double *runp = a.out + (row_start(s, i0, j, kn, 0) - a.base_off);
+    const int head = (int)((reinterpret_cast<uintptr_t>(runp) & 127) >> 3);  // doubles above a line boundary
+    const int nchunk = (head + n + 1) >> 1;
+    constexpr int NIT = (RUN / 2 + 8 + 63) / 64;
+    double2 v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {  // chunk q = the q-th 16 bytes from that boundary; LDS reads first
+      const int s0 = 2 * (lane + 64 * it) - head;
+      const int sa = s0 < 0 ? 0 : (s0 < n ? s0 : n - 1), sb = s0 + 1 < 0 ? 0 : (s0 + 1 < n ? s0 + 1 : n - 1);
+      v[it] = make_double2(sh_stage[sa], sh_stage[sb]);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int q = lane + 64 * it, s0 = 2 * q - head;
+      if (q < nchunk) {
+        if (s0 >= 0 && s0 + 1 < n) *reinterpret_cast<double2 *>(runp + s0) = v[it];
+        else if (s0 == -1) runp[0] = v[it].y;
+        else if (s0 == n - 1) runp[s0] = v[it].x;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // 2-D row sweep (plane strain, E2): the same scheme one dimension down.  A workgroup owns 64 x-consecutive
 // interior nodes and sweeps RS2_YC node rows in y.  Waves 0,1 = dof rows c = 0,1 (lane = node, 18 accumulators =
 // one CSR row: 9 neighbours x 2), wave 2 = record wave.  Premise, tested exactly on every element: axis-aligned
