@@ -230,6 +230,8 @@ def main():
             kname = "ELASTIC3D" if wl == "elastic3d" else "POISSON3D"
             fast = (level == 2) if wl == "elastic3d" else (level >= 1)
             kernel = f"k_assemble_rowsweep<{kname}>" if fast else f"k_assemble_sweep<{kname}>"
+            if wl == "poisson3d" and level == 2:
+                kernel = "k_assemble_p3_rect"
         traffic = measured_traffic(wl, nel, world, args)
         out = {
             "metric": "global assembly elements/sec + achieved HBM GB/s fraction",

@@ -316,7 +316,8 @@ int launch_rhs(femasm_plan *p, const femasm_material *mat, int bc, double *out, 
     const int64_t nl = p->s.dim[0] + p->s.dim[1] + (p->cke - p->s.cks);
     if (!p->lines) HIPCHK(hipMalloc(&p->lines, (size_t)nl * sizeof(double)));
     hipLaunchKernelGGL(k_poisson_rhs_lines, dim3(nblk(nl)), dim3(256), 0, p->stream, sl, a, p->lines);
-    const dim3 g3(nblk(p->s.dim[0]), (unsigned)p->s.dim[1], (unsigned)(s1 - s0));
+    if (p->s.dim[0] * p->s.dim[1] >= ((int64_t)1 << 32)) return fail(FEMASM_ERR_ARG, "node plane too large");
+    const dim3 g3(nblk(p->s.dim[0] * p->s.dim[1]), (unsigned)(s1 - s0 < 64 ? s1 - s0 : 64), 1);
     hipLaunchKernelGGL(k_poisson_rhs_rect, g3, dim3(256), 0, p->stream, sl, a, p->lines);
     HIPCHK(hipGetLastError());
   }
@@ -338,11 +339,13 @@ int launch_rhs(femasm_plan *p, const femasm_material *mat, int bc, double *out, 
       hipLaunchKernelGGL(k_rhs_elem_elastic_runs<false>, grid(0), dim3(64), 0, p->stream, sl, a);
     }
     else
-      hipLaunchKernelGGL(k_rhs_elem<KIND>, dim3(nblk(nel)), dim3(256), 0, p->stream, sl, a);
+      hipLaunchKernelGGL(k_rhs_elem<KIND>, dim3(nblk(nel) < 16384u ? nblk(nel) : 16384u), dim3(256), 0, p->stream, sl, a);
     HIPCHK(hipGetLastError());
   }
-  const dim3 ggrid = (T::NSD == 3) ? dim3(nblk(p->s.dim[0]), (unsigned)p->s.dim[1], (unsigned)(s1 - s0))
-                                   : dim3(nblk(p->s.dim[0]), (unsigned)(s1 - s0), 1);
+  // (the gather walks its logical grid with strides in y and z: capped launch)
+  auto capped = [](int64_t n, int64_t cap) { return (unsigned)(n < cap ? n : cap); };
+  const dim3 ggrid = (T::NSD == 3) ? dim3(nblk(p->s.dim[0]), capped(p->s.dim[1], 128), capped(s1 - s0, 32))
+                                   : dim3(nblk(p->s.dim[0]), capped(s1 - s0, 1024), 1);
   if constexpr (KIND == KIND_ELASTIC) {
     if (runs) hipLaunchKernelGGL((k_rhs_gather<KIND_ELASTIC, true>), ggrid, dim3(256), 0, p->stream, sl, a);
     else hipLaunchKernelGGL(k_rhs_gather<KIND>, ggrid, dim3(256), 0, p->stream, sl, a);

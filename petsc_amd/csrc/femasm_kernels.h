@@ -597,14 +597,9 @@ struct RArgs {
 };
 
 template <int KIND>
-__global__ __launch_bounds__(256) void k_rhs_elem(const Slab s, const RArgs a) {
+__device__ inline void rhs_elem_one(const Slab &s, const RArgs &a, int64_t e) {
   using T = Traits<KIND>;
   constexpr int NFE = T::NFE;
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= a.nel) return;
-  if constexpr (KIND == KIND_POISSON) {
-    if (a.rect != 0 && a.bad[3] == 0ULL) return;  // rectilinear mesh: k_poisson_rhs_rect has written b
-  }
   const int64_t M = s.dim[0], N = s.dim[1];
   const int64_t mx = M - 1, my = N - 1;
   double F[NFE];
@@ -730,6 +725,16 @@ __global__ __launch_bounds__(256) void k_rhs_elem(const Slab s, const RArgs a) {
     if constexpr (KIND == KIND_ELASTIC) a.elemF[ef_idx<NOUT>(e, q)] = F[q] + F[NOUT + q];
     else a.elemF[ef_idx<NOUT>(e, q)] = F[q];
   }
+}
+// grid-stride over the elements (a capped grid: the kernel is also launched when it only has to find out, on the
+// device, that the rectilinear P3 path has already written b)
+template <int KIND>
+__global__ __launch_bounds__(256) void k_rhs_elem(const Slab s, const RArgs a) {
+  if constexpr (KIND == KIND_POISSON) {
+    if (a.rect != 0 && a.bad[3] == 0ULL) return;  // rectilinear mesh: k_poisson_rhs_rect has written b
+  }
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < a.nel; e += (int64_t)gridDim.x * 256)
+    rhs_elem_one<KIND>(s, a, e);
 }
 
 // ---------------------------------------------------------------------------
@@ -1105,21 +1110,15 @@ __global__ __launch_bounds__(256) void k_op_elem(const Slab s, const RArgs a, do
 // RHS, pass 2: one thread per node; contributions added in the reference's element
 // order (k -> j -> i) (S3: Fe + Ge of an element enter as one term); then the Dirichlet value.
 // ---------------------------------------------------------------------------
-template <int KIND, bool RUNS = false>
-__global__ __launch_bounds__(256) void k_rhs_gather(const Slab s, const RArgs a) {
+template <int KIND, bool RUNS>
+__device__ inline void rhs_gather_node(const Slab &s, const RArgs &a, int64_t i, int64_t by, int64_t bz) {
   using T = Traits<KIND>;
   constexpr int NSD = T::NSD, DOF = T::DOF, NFE = T::NFE;
   const int64_t M = s.dim[0], N = s.dim[1];
   const int64_t mx = M - 1, my = N - 1;
-  // grid = (ceil(M/256), N or layers, layers or 1): no integer division
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= M) return;
-  if constexpr (KIND == KIND_POISSON) {
-    if (a.rect != 0 && a.bad[3] == 0ULL) return;  // rectilinear mesh: k_poisson_rhs_rect has written b
-  }
   int64_t j, k, q;
-  if constexpr (NSD == 3) { j = blockIdx.y; k = a.s0 + blockIdx.z; q = i + M * (j + N * (int64_t)blockIdx.z); }
-  else                    { j = a.s0 + blockIdx.y; k = 0; q = i + M * (int64_t)blockIdx.y; }
+  if constexpr (NSD == 3) { j = by; k = a.s0 + bz; q = i + M * (j + N * bz); }
+  else                    { j = a.s0 + by; k = 0; q = i + M * by; }
 
   double b[DOF];
 #pragma unroll
@@ -1208,6 +1207,18 @@ __global__ __launch_bounds__(256) void k_rhs_gather(const Slab s, const RArgs a)
 #pragma unroll
   for (int c = 0; c < DOF; c++) a.out[q * DOF + c] = b[c];
 }
+// logical grid (ceil(M/256), N or layers, layers or 1), walked with strides in y and z (the launch caps them)
+template <int KIND, bool RUNS = false>
+__global__ __launch_bounds__(256) void k_rhs_gather(const Slab s, const RArgs a) {
+  if constexpr (KIND == KIND_POISSON) {
+    if (a.rect != 0 && a.bad[3] == 0ULL) return;  // rectilinear mesh: k_poisson_rhs_rect has written b
+  }
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= s.dim[0]) return;
+  const int64_t ny = (Traits<KIND>::NSD == 3) ? s.dim[1] : a.s1 - a.s0, nz = (Traits<KIND>::NSD == 3) ? a.s1 - a.s0 : 1;
+  for (int64_t bz = blockIdx.z; bz < nz; bz += gridDim.z)
+    for (int64_t by = blockIdx.y; by < ny; by += gridDim.y) rhs_gather_node<KIND, RUNS>(s, a, i, by, bz);
+}
 
 // ---------------------------------------------------------------------------
 // P3 right-hand side on a rectilinear mesh (verified by k_check_rectilinear earlier on this stream, verdict in
@@ -1251,13 +1262,16 @@ __global__ __launch_bounds__(256) void k_poisson_rhs_rect(const Slab s, const RA
   if (!(a.rect != 0 && a.bad[3] == 0ULL)) return;
   constexpr double PI = 3.14159265358979323846264338327950288;
   const int64_t M = s.dim[0], N = s.dim[1];
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= M) return;
-  const int64_t j = blockIdx.y, k = a.s0 + blockIdx.z;
-  const int64_t q = i + M * (j + N * (int64_t)blockIdx.z);
-  double v = 0.0;
-  if (!is_bc_node(s, a.bc, i, j, k)) v = 3.0 * PI * PI * lines[i] * lines[M + j] * lines[M + N + (k - s.cks)];
-  a.out[q] = v;
+  const int64_t pq = (int64_t)blockIdx.x * 256 + threadIdx.x;  // node of the (i,j) plane: whole waves, coalesced
+  if (pq >= M * N) return;
+  const uint32_t j32 = (uint32_t)pq / (uint32_t)M;
+  const int64_t j = j32, i = pq - j * M;
+  for (int64_t bz = blockIdx.y; bz < a.s1 - a.s0; bz += gridDim.y) {
+    const int64_t k = a.s0 + bz;
+    double v = 0.0;
+    if (!is_bc_node(s, a.bc, i, j, k)) v = 3.0 * PI * PI * lines[i] * lines[M + j] * lines[M + N + (k - s.cks)];
+    a.out[pq + M * N * bz] = v;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1304,11 +1318,19 @@ __global__ __launch_bounds__(256) void k_check_rectilinear(const Slab s, const d
     const int64_t kl = r / N, j = r - kl * N;
     const double *row = coords + 3 * M * r;
     const double yref = coords[3 * (M * j) + 1], zref = coords[3 * (M * N * kl) + 2];
-    for (int t = threadIdx.x; t < n3; t += 256) {
-      const int c = t % 3;
-      const double v = row[t];
-      const double ref = c == 0 ? coords[t] : (c == 1 ? yref : zref);
-      bad |= v != ref;
+    for (int t0 = threadIdx.x; t0 < n3; t0 += 4 * 256) {  // four loads in flight per lane (clamped, streamed once)
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int t = t0 + 256 * u;
+        v[u] = __builtin_nontemporal_load(&row[t < n3 ? t : n3 - 1]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int t = (t0 + 256 * u < n3) ? t0 + 256 * u : n3 - 1, c = t % 3;
+        const double ref = c == 0 ? coords[t] : (c == 1 ? yref : zref);
+        bad |= v[u] != ref;
+      }
     }
   }
   if (__ballot(bad) != 0ULL && (threadIdx.x & 63) == 0) {

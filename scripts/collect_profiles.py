@@ -11,7 +11,7 @@ os.makedirs(dst, exist_ok=True)
 # workload tag -> (template name rocprof prints, label bench.py uses, nel)
 DOM = {
     "elastic3d": ("k_assemble_rowsweep<2>", "k_assemble_rowsweep<ELASTIC3D>", 128),
-    "poisson3d": ("k_assemble_rowsweep<0>", "k_assemble_rowsweep<POISSON3D>", 256),
+    "poisson3d": ("k_assemble_p3_rect", "k_assemble_p3_rect", 256),
     "elastic2d": ("k_assemble_rowsweep2d", "k_assemble_rowsweep2d", 2048),
 }
 kernels = []
