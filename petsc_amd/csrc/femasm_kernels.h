@@ -18,6 +18,13 @@
 //    reference's element order (k->j->i).
 #pragma once
 #include "femasm_device.h"
+// Profiling builds (never shipped: the build of __graft_entry__ does not define it).  -DFEMASM_EXP=n removes one
+// phase of a kernel so that its cost can be read off a timing (DESIGN.md section 3 quotes these):
+//   1  the global stores of the stiffness kernels (values are consumed by an empty asm)
+//   2  the contraction of the general kernels / direct lane-wise stores instead of the LDS transposition
+//   3  the geometry phase of the general kernels; in the row-sweep and RHS kernels: per-phase cycle counters
+//      (PH_* macros, dumped by femasm_plan_destroy)
+//   7  the record stores of k_rhs_elem_elastic_runs
 #ifndef FEMASM_EXP
 #define FEMASM_EXP 0
 #endif
