@@ -225,7 +225,7 @@ def main():
         achieved = st.bytes_main / (main_avg_ms * 1e-3) / 1e9
         level = plan.fast_path()
         if wl == "elastic2d":
-            kernel = "k_assemble_rowsweep2d" if level == 2 else "k_assemble_rows<PLANE_STRAIN2D>"
+            kernel = "k_assemble_e2_rect" if level == 2 else "k_assemble_rows<PLANE_STRAIN2D>"
         else:
             kname = "ELASTIC3D" if wl == "elastic3d" else "POISSON3D"
             fast = (level == 2) if wl == "elastic3d" else (level >= 1)

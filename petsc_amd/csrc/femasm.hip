@@ -171,16 +171,16 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
       // interior nodes: 2-D row sweep (rectangles, one (E,nu) per element; verified in the kernel)
       const Box b{1, M - 1, 0, 1, y0, y1};
       const KArgs a = make_kargs<KIND>(p, mat, bc, out, b, s0, iface);
-      dim3 grid((unsigned)((b.x1 - b.x0 + RS2_TX - 1) / RS2_TX), (unsigned)((y1 - y0 + RS2_YC - 1) / RS2_YC), 1);
+      dim3 grid((unsigned)((b.x1 - b.x0 + RS2_TX - 1) / RS2_TX), (unsigned)((y1 - y0 + E2W_YC - 1) / E2W_YC), 1);
       if (timed) HIPCHK(hipEventRecord(p->ev[4], p->stream));
-      hipLaunchKernelGGL(k_assemble_rowsweep2d, grid, dim3(192), 0, p->stream, p->s, a);
+      hipLaunchKernelGGL(k_assemble_e2_rect, grid, dim3(64), 0, p->stream, p->s, a);
       HIPCHK(hipGetLastError());
       p->used_fast = true;
       if (timed) {
         HIPCHK(hipEventRecord(p->ev[5], p->stream));
         const double nint = (double)(M - 2) * (double)(y1 - y0);
-        p->bytes_main = 8.0 * nint * 36.0 + 8.0 * 2.0 * (double)M * (y1 - y0 + 2) +
-                        (aos2 ? 16.0 * 4.0 * (double)(M - 1) * (y1 - y0 + 1) : 0.0);
+        // stores of the interior rows + E,nu at the Gauss points (the coordinates are read by the pre-pass)
+        p->bytes_main = 8.0 * nint * 36.0 + (aos2 ? 16.0 * 4.0 * (double)(M - 1) * (y1 - y0 + 1) : 0.0);
       }
       // the four edges of the node grid (Dirichlet columns i = 0, M-1 and the rows j = 0, N-1): brick kernel
       int rc2 = launch_brick<KIND>(p, mat, bc, out, Box{0, 1, 0, 1, y0, y1}, s0, iface);
@@ -269,8 +269,16 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
 // that rely on it (flags bad[1] and bad[3]).
 int launch_rect_check(femasm_plan *p) {
   p->rect_checked = false;
-  if (p->s.nsd != 3 || p->fast_level != 2) return 0;
+  if (p->fast_level != 2) return 0;
   const int64_t nlayers = p->cke - p->s.cks;
+  if (p->s.nsd == 2) {
+    int64_t nb2 = nlayers < (int64_t)p->ncu * 16 ? nlayers : (int64_t)p->ncu * 16;
+    hipLaunchKernelGGL(k_check_rectilinear2d, dim3((unsigned)nb2), dim3(256), 0, p->stream, p->s, p->coords, nlayers,
+                       p->bad + 1);
+    HIPCHK(hipGetLastError());
+    p->rect_checked = true;
+    return 0;
+  }
   int64_t nb = p->s.dim[1] * nlayers;
   if (nb > (int64_t)p->ncu * 16) nb = (int64_t)p->ncu * 16;
   hipLaunchKernelGGL(k_check_rectilinear, dim3((unsigned)nb), dim3(256), 0, p->stream, p->s, p->coords, nlayers,

@@ -1346,6 +1346,26 @@ __global__ __launch_bounds__(256) void k_check_rectilinear(const Slab s, const d
   }
 }
 
+// the same test for the 2-D drivers: x depends on i only, y on j only
+__global__ __launch_bounds__(256) void k_check_rectilinear2d(const Slab s, const double *coords, int64_t nrows,
+                                                             unsigned long long *flag) {
+  const int64_t M = s.dim[0];
+  const int n2 = (int)(2 * M);
+  bool bad = false;
+  for (int64_t r = blockIdx.x; r < nrows; r += gridDim.x) {
+    const double *row = coords + 2 * M * r;
+    const double yref = row[1];
+    for (int t = threadIdx.x; t < n2; t += 256) {
+      const double v = __builtin_nontemporal_load(&row[t]);
+      bad |= v != ((t & 1) ? yref : coords[t]);
+    }
+  }
+  if (__ballot(bad) != 0ULL && (threadIdx.x & 63) == 0) {
+    atomicAdd(flag, 1ULL);
+    atomicAdd(flag + 2, 1ULL);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // N1: fill of the GaussPointCoefficients array on device (the step before the path; S3:1243-1363, E2:618-670).
 // S3: 32 lanes per element, lane q < 24 = face Gauss point q (position, E_B, nu_B, grad u of the manufactured

@@ -1001,12 +1001,9 @@ __global__ __launch_bounds__(64) void k_assemble_p3_rect(const Slab s, const KAr
 }
 
 // ---------------------------------------------------------------------------
-// 2-D row sweep (plane strain, E2): the same scheme one dimension down.  A workgroup owns 64 x-consecutive
-// interior nodes and sweeps RS2_YC node rows in y.  Waves 0,1 = dof rows c = 0,1 (lane = node, 18 accumulators =
-// one CSR row: 9 neighbours x 2), wave 2 = record wave.  Premise, tested exactly on every element: axis-aligned
-// rectangle with one (E,nu) over its 4 Gauss points.  Record: d11 a_i^2 (2), d44 a_i^2 (2), d12 a_x a_y, d44 a_x a_y.
-// The 64 node blocks of a node row (36 doubles each) are one 18 KB run of the CSR array: both row waves deposit with
-// all lanes, then write it in whole aligned lines.
+// 2-D fast path (plane strain, E2).  Premise: rectilinear mesh (k_check_rectilinear2d) with one (E,nu) over the four
+// Gauss points of an element.  Record of an element: d11 a_i^2 (2), d44 a_i^2 (2), d12 a_x a_y, d44 a_x a_y with
+// a_i = 1/J_ii; R_ab = sum_p dN_a/dxi dN_b/dxi^T a compile-time tensor (closed form checked against the Gauss sum).
 // ---------------------------------------------------------------------------
 struct RefR2 { double R[4][4][2][2]; };
 constexpr RefR2 make_refR2() {
@@ -1040,34 +1037,103 @@ constexpr bool refR2_finite() {
 static_assert(refR2_finite(), "2-D reference tensor R_ab: closed form disagrees with the Gauss sum");
 __device__ const RefR2 d_refR2 = make_refR2();
 
-constexpr int RS2_TX = 64, RS2_YC = 32, RS2_NS = 72, RS2_NXX = RS2_TX + 2, RS2_NEX = RS2_TX + 1;
-constexpr int RS2_ROW = 18, RS2_NB = 36, RS2_RUN = RS2_TX * RS2_NB;
+constexpr int RS2_TX = 64;              // x-consecutive interior nodes of a run
+constexpr int RS2_ROW = 18, RS2_NB = 36;  // values of a CSR row / of a node block (2 dof rows)
 
-template <int C>
-__device__ inline void rowsweep2d_row_wave(const Slab &s, const KArgs &a, const double2 *sh_rec, double *sh_stage,
-                                           unsigned *sh_cnt, int lane, int64_t i0, int64_t yc0, int ny) {
-  constexpr int NS = RS2_NS;
+// ---------------------------------------------------------------------------
+// E2 on a verified rectilinear mesh (level 2), autonomous waves as in k_assemble_p3_rect: a row of 64 x-consecutive
+// interior nodes is an 18 KB run (2 dof rows x 18 values per node) that one wave owns.  Lane = node, 36
+// accumulators; the six record numbers of an element follow from the two coordinate lines and its (E,nu) (read by
+// the lanes either side of it one step ahead, all four Gauss points compared bitwise: bad[1] on a mismatch), with
+// the operations of k_assemble_rowsweep2d's record wave in the same order.  No record wave, no hand-shake.
+// ---------------------------------------------------------------------------
+constexpr int E2W_YC = 32;
+__global__ __launch_bounds__(64) void k_assemble_e2_rect(const Slab s, const KArgs a) {
+  constexpr int NB = RS2_NB, RUN = RS2_TX * NB;
+  __shared__ __attribute__((aligned(16))) double sh_stage[RUN];
+  const int lane = threadIdx.x;
+  const int64_t M = s.dim[0];
+  const int64_t i0 = a.x0 + (int64_t)blockIdx.x * RS2_TX;
+  const int64_t yc0 = a.s0 + (int64_t)blockIdx.y * E2W_YC;
+  const int64_t yc1 = (yc0 + E2W_YC < a.s1) ? yc0 + E2W_YC : a.s1;
+  const int ny = (int)(yc1 - yc0);
   const int nvx = (a.x1 - i0 < RS2_TX) ? (int)(a.x1 - i0) : RS2_TX;
-  int q3 = 0;
-  unsigned epoch = 0;
+  const int64_t i = (lane < nvx) ? i0 + lane : i0 + nvx - 1;  // idle lanes repeat the last node
+  const bool aos = a.mat_layout == 0;
+  const double xm = a.coords[2 * (i - 1)], xc = a.coords[2 * i], xp = a.coords[2 * (i + 1)];
+  const double Jx[2] = {0.5 * (xc - xm), 0.5 * (xp - xc)};
+  const double ax[2] = {1.0 / Jx[0], 1.0 / Jx[1]};
+  auto yline = [&](int64_t j) {
+    j = j < s.cks ? s.cks : (j > a.cke - 1 ? a.cke - 1 : j);
+    return a.coords[2 * (M * (j - s.cks)) + 1];
+  };
+  // E[4], nu[4] of the elements i-1, i of element row L (clamped to the rows this rank holds: never masked)
+  auto load_mat = [&](int64_t L, double (*m)[8]) {
+    if (!aos) return;
+    const int64_t Lc = L < s.els ? s.els : (L > s.ele - 1 ? s.ele - 1 : L);
+#pragma unroll
+    for (int ox = 0; ox < 2; ox++) {
+      const double *mq = a.gp + ((i - 1 + ox) + (M - 1) * (Lc - s.mat_e_ks)) * a.mat_stride + 8;
+#pragma unroll
+      for (int q = 0; q < 8; q++) m[ox][q] = mq[q];
+    }
+  };
+  // records (pd0, pd1, pe0, pe1, po, pq) of the elements i-1, i of element row L
+  auto records = [&](int64_t L, const double (*m)[8], double (*rec)[6]) {
+    const bool rowok = L >= s.els && L < s.ele;
+    const double J11 = rowok ? 0.5 * (yline(L + 1) - yline(L)) : 1.0;
+    const double ay = 1.0 / J11;
+#pragma unroll
+    for (int ox = 0; ox < 2; ox++) {
+      double E = a.E, nu = a.nu;
+      bool ok = true;
+      if (aos) {
+        E = m[ox][0];
+        nu = m[ox][4];
+#pragma unroll
+        for (int q = 1; q < 4; q++) ok = ok && m[ox][q] == E && m[ox][4 + q] == nu;
+      }
+      if (rowok && !ok) atomicAdd(a.bad + 1, 1ULL);
+      const double wJ = 1.0 * (Jx[ox] * J11);
+      if (rowok && !(wJ > 0.0)) atomicAdd(a.bad, 1ULL);
+      double d11, d12, d44;
+      scaled_coefs<KIND_PLANE>(E, nu, wJ, d11, d12, d44);
+      rec[ox][0] = rowok ? d11 * (ax[ox] * ax[ox]) : 0.0;
+      rec[ox][1] = rowok ? d11 * (ay * ay) : 0.0;
+      rec[ox][2] = rowok ? d44 * (ax[ox] * ax[ox]) : 0.0;
+      rec[ox][3] = rowok ? d44 * (ay * ay) : 0.0;
+      rec[ox][4] = rowok ? d12 * (ax[ox] * ay) : 0.0;
+      rec[ox][5] = rowok ? d44 * (ax[ox] * ay) : 0.0;
+    }
+  };
+  double mcur[2][8], mnext[2][8], rlo[2][6], rhi[2][6];
+#pragma unroll
+  for (int ox = 0; ox < 2; ox++)
+#pragma unroll
+    for (int q = 0; q < 8; q++) mcur[ox][q] = mnext[ox][q] = 0.0;
+  load_mat(yc0 - 1, mcur);
+  records(yc0 - 1, mcur, rlo);
+  load_mat(yc0, mnext);
   for (int st = 0; st < ny; st++) {
     const int64_t jn = yc0 + st;
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-    const int q3a = (q3 == 2) ? 0 : q3 + 1;
-    __syncthreads();  // records of element rows jn-1 (ring slot q3) and jn (slot q3a) are complete
-    double acc[RS2_ROW];
 #pragma unroll
-    for (int q = 0; q < RS2_ROW; q++) acc[q] = 0.0;
+    for (int ox = 0; ox < 2; ox++)
 #pragma unroll
-    for (int oy = -1; oy <= 0; oy++) {
-      const double2 *rl = sh_rec + (oy ? q3 : q3a) * (3 * NS);
+      for (int q = 0; q < 8; q++) mcur[ox][q] = mnext[ox][q];
+    load_mat(jn + 1, mnext);  // one step ahead: issued before this step's stores
+    records(jn, mcur, rhi);
+    double acc[2][RS2_ROW];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int q = 0; q < RS2_ROW; q++) acc[c][q] = 0.0;
+#pragma unroll
+    for (int oy = -1; oy <= 0; oy++)
 #pragma unroll
       for (int ox = -1; ox <= 0; ox++) {
-        const double2 *rp = rl + (ln + 1 + ox);
-        const double2 r0 = rp[0], r1 = rp[NS], r2 = rp[2 * NS];
-        const double pd[2] = {r0.x, r0.y}, pe[2] = {r1.x, r1.y};
-        const double po = r2.x, pq = r2.y;
+        const double *r = oy ? rlo[ox + 1] : rhi[ox + 1];
+        const double pd[2] = {r[0], r[1]}, pe[2] = {r[2], r[3]};
+        const double po = r[4], pq = r[5];
         const int ia = quad_idx(-ox, -oy);
 #pragma unroll
         for (int by = 0; by <= 1; by++)
@@ -1075,206 +1141,52 @@ __device__ inline void rowsweep2d_row_wave(const Slab &s, const KArgs &a, const 
           for (int bx = 0; bx <= 1; bx++) {
             const double(*R)[2] = d_refR2.R[ia][quad_idx(bx, by)];
             const int t = (oy + by + 1) * 3 + (ox + bx + 1);
-            acc[2 * t + C] = fma(R[C][C], pd[C], fma(R[1 - C][1 - C], pe[1 - C], acc[2 * t + C]));
-            acc[2 * t + 1 - C] = fma(R[C][1 - C], po, fma(R[1 - C][C], pq, acc[2 * t + 1 - C]));
+#pragma unroll
+            for (int C = 0; C < 2; C++) {
+              acc[C][2 * t + C] = fma(R[C][C], pd[C], fma(R[1 - C][1 - C], pe[1 - C], acc[C][2 * t + C]));
+              acc[C][2 * t + 1 - C] = fma(R[C][1 - C], po, fma(R[1 - C][C], pq, acc[C][2 * t + 1 - C]));
+            }
           }
       }
-    }
-    row_waves_sync<2>(sh_cnt, epoch, ln, a.bad);  // the previous run has left the staging buffer
+#pragma unroll
+    for (int ox = 0; ox < 2; ox++)
+#pragma unroll
+      for (int q = 0; q < 6; q++) rlo[ox][q] = rhi[ox][q];
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();  // the previous step's reads of the stage are done
     {
-      double2 *dst = reinterpret_cast<double2 *>(sh_stage + ln * RS2_NB + C * RS2_ROW);
+      double2 *dst = reinterpret_cast<double2 *>(sh_stage + lane * NB);
 #pragma unroll
-      for (int q = 0; q < RS2_ROW / 2; q++) dst[q] = make_double2(acc[2 * q], acc[2 * q + 1]);
+      for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int q = 0; q < RS2_ROW / 2; q++) dst[c * (RS2_ROW / 2) + q] = make_double2(acc[c][2 * q], acc[c][2 * q + 1]);
     }
-    row_waves_sync<2>(sh_cnt, epoch, ln, a.bad);  // run complete in LDS, in HBM order
-    {
-      const int n = nvx * RS2_NB;
-      double *runp = a.out + (row_start(s, i0, jn, 0, 0) - a.base_off);
-      const int head = (int)((reinterpret_cast<uintptr_t>(runp) & 127) >> 3);
-      const int nchunk = (head + n + 1) >> 1;
-      const int ct = 64 * C + ln;
-      constexpr int NIT = (RS2_RUN / 2 + 8 + 127) / 128;
-      double2 v[NIT];
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const int n = nvx * NB;
+    double *runp = a.out + (row_start(s, i0, jn, 0, 0) - a.base_off);
+    const int head = (int)((reinterpret_cast<uintptr_t>(runp) & 127) >> 3);
+    const int nchunk = (head + n + 1) >> 1;
+    constexpr int NIT = (RUN / 2 + 8 + 63) / 64;
+    double2 v[NIT];
 #pragma unroll
-      for (int it = 0; it < NIT; it++) {
-        const int s0 = 2 * (ct + 128 * it) - head;
-        const int sa = s0 < 0 ? 0 : (s0 < n ? s0 : n - 1), sb = s0 + 1 < 0 ? 0 : (s0 + 1 < n ? s0 + 1 : n - 1);
-        v[it] = make_double2(sh_stage[sa], sh_stage[sb]);
-      }
+    for (int it = 0; it < NIT; it++) {
+      const int s0 = 2 * (lane + 64 * it) - head;
+      const int sa = s0 < 0 ? 0 : (s0 < n ? s0 : n - 1), sb = s0 + 1 < 0 ? 0 : (s0 + 1 < n ? s0 + 1 : n - 1);
+      v[it] = make_double2(sh_stage[sa], sh_stage[sb]);
+    }
 #pragma unroll
-      for (int it = 0; it < NIT; it++) {
-        const int q = ct + 128 * it, s0 = 2 * q - head;
-        if (q < nchunk) {
-          if (s0 >= 0 && s0 + 1 < n) *reinterpret_cast<double2 *>(runp + s0) = v[it];
-          else if (s0 == -1) runp[0] = v[it].y;
-          else if (s0 == n - 1) runp[s0] = v[it].x;
-        }
+    for (int it = 0; it < NIT; it++) {
+      const int q = lane + 64 * it, s0 = 2 * q - head;
+      if (q < nchunk) {
+        if (s0 >= 0 && s0 + 1 < n) *reinterpret_cast<double2 *>(runp + s0) = v[it];
+        else if (s0 == -1) runp[0] = v[it].y;
+        else if (s0 == n - 1) runp[s0] = v[it].x;
       }
     }
-    q3 = q3a;
   }
 }
 
-__global__ __launch_bounds__(192) void k_assemble_rowsweep2d(const Slab s, const KArgs a) {
-  constexpr int NS = RS2_NS, NXX = RS2_NXX, NEX = RS2_NEX;
-  __shared__ double2 sh_rec[3 * 3 * NS];   // ring: element row L0+q in slot q % 3
-  __shared__ __attribute__((aligned(16))) double sh_stage[RS2_RUN];
-  __shared__ double sh_x[3][NXX * 2];      // ring of node rows (record wave only)
-  __shared__ unsigned sh_cnt;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t M = s.dim[0];
-  const int64_t i0 = a.x0 + (int64_t)blockIdx.x * RS2_TX;
-  const int64_t yc0 = a.s0 + (int64_t)blockIdx.y * RS2_YC;
-  const int64_t yc1 = (yc0 + RS2_YC < a.s1) ? yc0 + RS2_YC : a.s1;
-  const int ny = (int)(yc1 - yc0);
-  const int64_t L0 = yc0 - 1;
-  if (tid == 0) sh_cnt = 0;
-  if (wu < 2) {
-    __syncthreads();
-    if (wu == 0) rowsweep2d_row_wave<0>(s, a, sh_rec, sh_stage, &sh_cnt, lane, i0, yc0, ny);
-    else         rowsweep2d_row_wave<1>(s, a, sh_rec, sh_stage, &sh_cnt, lane, i0, yc0, ny);
-    return;
-  }
-  // ------------------------------- record wave -------------------------------
-  const bool aos = a.mat_layout == 0;
-  auto load_row = [&](int64_t gj, double (*cr)[2], int ln) {  // node row gj of the halo'd tile -> registers
-    gj = gj < s.cks ? s.cks : (gj > a.cke - 1 ? a.cke - 1 : gj);
-#pragma unroll
-    for (int ps = 0; ps < 2; ps++) {
-      const int q = ln + 64 * ps;
-      if (q < NXX) {
-        int64_t gi = i0 - 1 + q;
-        gi = gi < 0 ? 0 : (gi > M - 1 ? M - 1 : gi);
-        const double *src = a.coords + 2 * (gi + M * (gj - s.cks));
-        cr[ps][0] = src[0];
-        cr[ps][1] = src[1];
-      }
-    }
-  };
-  auto commit_row = [&](int slot, const double (*cr)[2], int ln) {
-#pragma unroll
-    for (int ps = 0; ps < 2; ps++) {
-      const int q = ln + 64 * ps;
-      if (q < NXX) {
-        sh_x[slot][2 * q] = cr[ps][0];
-        sh_x[slot][2 * q + 1] = cr[ps][1];
-      }
-    }
-  };
-  auto load_mat = [&](int64_t L, double (*mraw)[8], int ln) {  // E[4], nu[4] of the elements of row L
-    if (!aos) return;
-#pragma unroll
-    for (int ps = 0; ps < 2; ps++) {
-      const int e = ln + 64 * ps;
-      const int64_t gex = i0 - 1 + e;
-      if (e < NEX && gex >= 0 && gex < M - 1 && L >= s.els && L < s.ele) {
-        const double *mq = a.gp + (gex + (M - 1) * (L - s.mat_e_ks)) * a.mat_stride + 8;
-#pragma unroll
-        for (int q = 0; q < 8; q++) mraw[ps][q] = mq[q];
-      }
-    }
-  };
-  auto build = [&](int64_t L, const double *xb, const double *xt, double2 *recbuf, const double (*mraw)[8], int ln) {
-#pragma unroll
-    for (int ps = 0; ps < 2; ps++) {
-      const int e = ln + 64 * ps;
-      if (e >= NEX) continue;
-      const int64_t gex = i0 - 1 + e;
-      double2 *dst = recbuf + e;
-      if (!(gex >= 0 && gex < M - 1 && L >= s.els && L < s.ele)) {
-#pragma unroll
-        for (int q = 0; q < 3; q++) dst[q * NS] = make_double2(0.0, 0.0);
-        continue;
-      }
-      // nodes: 0 (0,0), 1 (0,1), 2 (1,1), 3 (1,0)
-      const double x0[2] = {xb[2 * e], xb[2 * e + 1]}, x3[2] = {xb[2 * e + 2], xb[2 * e + 3]};
-      const double x1[2] = {xt[2 * e], xt[2 * e + 1]}, x2[2] = {xt[2 * e + 2], xt[2 * e + 3]};
-      bool ok = true;
-      double J[2][2];
-#pragma unroll
-      for (int d = 0; d < 2; d++) {
-        const double e1 = x3[d] - x0[d], e2 = x1[d] - x0[d];
-        ok = ok && (x2[d] - x1[d] == e1) && (x2[d] - x3[d] == e2);
-        J[0][d] = 0.5 * e1;
-        J[1][d] = 0.5 * e2;
-      }
-      ok = ok && J[0][1] == 0.0 && J[1][0] == 0.0;
-      double E = a.E, nu = a.nu;
-      if (aos) {
-        E = mraw[ps][0];
-        nu = mraw[ps][4];
-#pragma unroll
-        for (int q = 1; q < 4; q++) ok = ok && mraw[ps][q] == E && mraw[ps][4 + q] == nu;
-      }
-      if (!ok) atomicAdd(a.bad + 1, 1ULL);
-      const double wJ = 1.0 * (J[0][0] * J[1][1]);
-      if (!(wJ > 0.0)) atomicAdd(a.bad, 1ULL);
-      const double ax = 1.0 / J[0][0], ay = 1.0 / J[1][1];
-      double d11, d12, d44;
-      scaled_coefs<KIND_PLANE>(E, nu, wJ, d11, d12, d44);
-      dst[0] = make_double2(d11 * (ax * ax), d11 * (ay * ay));
-      dst[NS] = make_double2(d44 * (ax * ax), d44 * (ay * ay));
-      dst[2 * NS] = make_double2(d12 * (ax * ay), d44 * (ax * ay));
-    }
-  };
-  auto lds_fence = [&]() {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-  };
-  double cr[2][2][2], mraw[2][2][8];
-#pragma unroll
-  for (int p = 0; p < 2; p++)
-#pragma unroll
-    for (int ps = 0; ps < 2; ps++) {
-      cr[p][ps][0] = cr[p][ps][1] = 0.0;
-#pragma unroll
-      for (int q = 0; q < 8; q++) mraw[p][ps][q] = 0.0;
-    }
-  // prologue: node rows L0..L0+2, records of element rows L0 and L0+1; requests for steps 0 and 1
-#pragma unroll 1
-  for (int q = 0; q < 3; q++) {
-    load_row(L0 + q, cr[0], lane);
-    commit_row(q, cr[0], lane);
-  }
-#pragma unroll 1
-  for (int q = 0; q < 2; q++) {
-    load_mat(L0 + q, mraw[0], lane);
-    lds_fence();
-    build(L0 + q, sh_x[q], sh_x[q + 1], sh_rec + q * (3 * NS), mraw[0], lane);
-  }
-  load_row(L0 + 3, cr[0], lane);
-  load_mat(L0 + 2, mraw[0], lane);
-  load_row(L0 + 4, cr[1], lane);
-  load_mat(L0 + 3, mraw[1], lane);
-  __syncthreads();
-  int q3 = 0;
-  auto step = [&](int st, double (*crp)[2], double (*mrawp)[8]) {
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-    const int q3a = (q3 == 2) ? 0 : q3 + 1, q3b = (q3a == 2) ? 0 : q3a + 1;
-    __syncthreads();
-    if (st + 1 < ny) {  // records of element row L0+st+2
-      commit_row(q3, crp, ln);  // node row L0+st+3 replaces row L0+st
-      double mcur[2][8];
-#pragma unroll
-      for (int ps = 0; ps < 2; ps++)
-#pragma unroll
-        for (int q = 0; q < 8; q++) mcur[ps][q] = mrawp[ps][q];
-      if (st + 3 < ny) {
-        load_row(L0 + st + 5, crp, ln);
-        load_mat(L0 + st + 4, mrawp, ln);
-      }
-      lds_fence();
-      build(L0 + st + 2, sh_x[q3b], sh_x[q3], sh_rec + q3b * (3 * NS), mcur, ln);
-    }
-    q3 = q3a;
-  };
-  for (int st = 0; st < ny; st += 2) {
-    step(st, cr[0], mraw[0]);
-    if (st + 1 < ny) step(st + 1, cr[1], mraw[1]);
-  }
-}
 
 // ---------------------------------------------------------------------------
 // Dirichlet rows (A10/A11): one workgroup per x-row of nodes (j,k), one wave per Dirichlet node at a time; the

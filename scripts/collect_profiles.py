@@ -12,7 +12,7 @@ os.makedirs(dst, exist_ok=True)
 DOM = {
     "elastic3d": ("k_assemble_rowsweep<2>", "k_assemble_rowsweep<ELASTIC3D>", 128),
     "poisson3d": ("k_assemble_p3_rect", "k_assemble_p3_rect", 256),
-    "elastic2d": ("k_assemble_rowsweep2d", "k_assemble_rowsweep2d", 2048),
+    "elastic2d": ("k_assemble_e2_rect", "k_assemble_e2_rect", 2048),
 }
 kernels = []
 for tag, (pat, label, nel) in DOM.items():
