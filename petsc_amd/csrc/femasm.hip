@@ -88,6 +88,7 @@ struct femasm_plan {
   bool own_stream = false;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int ncu = 256;                       // compute units of the device
+  int rhs_wg_per_cu[2] = {0, 0};       // resident workgroups per CU of k_rhs_elem_elastic_runs<false / true>
   bool rect_checked = false;           // k_check_rectilinear ran on the stream in this call (its verdict is bad[3])
   bool iface_done = false;             // femasm_assemble_interface already filled the send buffer for the next call
   bool time_main = false;              // record ev[4], ev[5] around the dominant K kernel of the main pass
@@ -331,12 +332,10 @@ int launch_rhs(femasm_plan *p, const femasm_material *mat, int bc, double *out, 
   }
   if (do_elem && nel > 0) {
     if (runs) {
-      // persistent one-wave workgroups: one resident set
-      static int wg_per_cu[2] = {0, 0}, ncu = 0;
+      // persistent one-wave workgroups: one resident set (occupancy queried once per plan)
+      int *wg_per_cu = p->rhs_wg_per_cu;
+      const int ncu = p->ncu;
       if (!wg_per_cu[0]) {
-        hipDeviceProp_t prop;
-        HIPCHK(hipGetDeviceProperties(&prop, p->device));
-        ncu = prop.multiProcessorCount;
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu[1], k_rhs_elem_elastic_runs<true>, 64, 0));
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu[0], k_rhs_elem_elastic_runs<false>, 64, 0));
         if (wg_per_cu[0] < 1) wg_per_cu[0] = 1;

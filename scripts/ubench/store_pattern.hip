@@ -143,6 +143,46 @@ __global__ __launch_bounds__(256) void p8(double *out, int64_t ntile, int iters)
   }
 }
 
+// P9: the autonomous-wave form for dof 3 (what k_assemble_p3_rect / k_assemble_e2_rect do for dof 1 / 2): one wave
+// per workgroup owns a run of 21 nodes x 243 doubles (40.8 KB stage, 3 waves per CU), lane = (node, dof row) with
+// NFMA dependent-free FMAs on its 81 accumulators per step, deposit, then 16 B per lane from the line boundary below
+// the run.  Skeleton only: is a wave-private run worth building for the elastic kernel?
+template <int NFMA>
+__global__ __launch_bounds__(64) void p9(double *out, int64_t nrun) {
+  constexpr int RL = 21, RUN = RL * NB;
+  __shared__ double stage[RUN];
+  const int lane = threadIdx.x, n = lane % RL, c = lane / RL;
+  double acc[81];
+  for (int q = 0; q < 81; q++) acc[q] = lane + q;
+  for (int64_t r = blockIdx.x; r < nrun; r += gridDim.x) {
+    const double f = 1.0 + 1e-9 * (double)r;
+#pragma unroll
+    for (int k = 0; k < NFMA / 81; k++)
+#pragma unroll
+      for (int q = 0; q < 81; q++) acc[q] = fma(acc[q], f, 0.5);
+    __builtin_amdgcn_wave_barrier();
+    if (c < 3)
+#pragma unroll
+      for (int q = 0; q < 81; q++) stage[n * NB + c * 81 + q] = acc[q];
+    __builtin_amdgcn_wave_barrier();
+    double *runp = out + r * RUN;
+    const int head = (int)((reinterpret_cast<uintptr_t>(runp) & 127) >> 3);
+    const int nchunk = (head + RUN + 1) >> 1;
+    constexpr int NIT = (RUN / 2 + 8 + 63) / 64;
+#pragma unroll 8
+    for (int it = 0; it < NIT; it++) {
+      const int q = lane + 64 * it, s0 = 2 * q - head;
+      const int sa = s0 < 0 ? 0 : (s0 < RUN ? s0 : RUN - 1), sb = s0 + 1 < 0 ? 0 : (s0 + 1 < RUN ? s0 + 1 : RUN - 1);
+      const double2 v = make_double2(stage[sa], stage[sb]);
+      if (q < nchunk) {
+        if (s0 >= 0 && s0 + 1 < RUN) *reinterpret_cast<double2 *>(runp + s0) = v;
+        else if (s0 == -1) runp[0] = v.y;
+        else if (s0 == RUN - 1) runp[s0] = v.x;
+      }
+    }
+  }
+}
+
 template <typename F>
 void timeit(const char *name, double bytes, F launch) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -157,6 +197,13 @@ int main() {
   const int64_t nnode = 2097152, ntile = nnode / 64;
   const double bytes = 8.0 * NB * nnode;
   double *out; hipMalloc(&out, (size_t)bytes + 4096);
+  {
+    const int64_t nrun = nnode / 21;
+    printf("--- autonomous waves, 3 per CU ---\n");
+    timeit("P9 wave-private 21-node runs, no FMAs", 8.0 * NB * 21 * nrun, [&] { p9<0><<<256 * 3, 64>>>(out, nrun); });
+    timeit("P9 wave-private 21-node runs, 486 FMAs/step", 8.0 * NB * 21 * nrun, [&] { p9<486><<<256 * 3, 64>>>(out, nrun); });
+    timeit("P9 wave-private 21-node runs, 1458 FMAs/step", 8.0 * NB * 21 * nrun, [&] { p9<1458><<<256 * 3, 64>>>(out, nrun); });
+  }
   for (int wgcu : {2, 4}) {
     const int lds = wgcu == 2 ? 70000 : 36000;
     const int grid = 256 * wgcu, iters = (int)((ntile + grid - 1) / grid);
