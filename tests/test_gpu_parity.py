@@ -96,6 +96,8 @@ CASES = [
     ("e2", (2, 2)), ("e2", (9, 7)), ("e2", (40, 21)), ("e2", (17, 5)), ("e2", (3, 50)),
     ("s3", (2, 2, 2)), ("s3", (4, 4, 4)), ("s3", (8, 6, 7)), ("s3", (5, 9, 3)), ("s3", (13, 4, 6)),
     ("s3", (38, 5, 36)),
+    # odd mid-size meshes: several tiles / runs / chunks in every direction, none a multiple of the tile sizes
+    ("p3", (131, 37, 70)), ("e2", (301, 137)), ("s3", (45, 23, 36)),
 ]
 
 
