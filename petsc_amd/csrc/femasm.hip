@@ -245,7 +245,8 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
       } else {
         dim3 grid((unsigned)((b.x1 - b.x0 + SW_TX - 1) / SW_TX), (unsigned)((b.y1 - b.y0 + SW_TY - 1) / SW_TY),
                   (unsigned)((z1 - z0 + SW_ZC - 1) / SW_ZC));
-        hipLaunchKernelGGL(k_assemble_sweep<KIND>, grid, dim3(256), 0, p->stream, p->s, a);
+        if (KIND == KIND_POISSON) hipLaunchKernelGGL(k_assemble_sweep_p3, grid, dim3(256), 0, p->stream, p->s, a);
+        else hipLaunchKernelGGL(k_assemble_sweep<KIND>, grid, dim3(256), 0, p->stream, p->s, a);
       }
       HIPCHK(hipGetLastError());
       if (timed) HIPCHK(hipEventRecord(p->ev[5], p->stream));

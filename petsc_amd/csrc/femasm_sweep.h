@@ -310,6 +310,174 @@ __global__ __launch_bounds__(256, 2) void k_assemble_sweep(const Slab s, const K
 }
 
 // ---------------------------------------------------------------------------
+// General path for P3 (any hexahedra).  With g_a = iJ^T ghat_a the Gauss-point term w detJ g_a.g_b is
+// ghat_a^T C_p ghat_b, C_p = detJ_p iJ_p^T iJ_p: the reference gradients ghat are compile-time numbers, so a
+// record is the six entries of C_p (48 B instead of the 200 B of eight physical gradients) and the products
+// ghat_a[k] ghat_b[l] fold into literals once the Gauss-point loop is unrolled.  Same tile, roles and stores as
+// k_assemble_sweep; all 8 x 85 records of an element layer are built in one go by all four waves (wave w: Gauss
+// points 2w, 2w+1), so a step has three barriers instead of nine.  LDS reads per node 12.8 KB -> 3 KB.
+// ---------------------------------------------------------------------------
+struct RefGP { double c[8][8][8][6]; };  // [p][a][b]: coefficients of C00, C11, C22, C01, C02, C12
+constexpr RefGP make_refGP() {
+  RefGP o{};
+  const Tab3 t = make_tab3();
+  for (int p = 0; p < 8; p++)
+    for (int a = 0; a < 8; a++)
+      for (int b = 0; b < 8; b++) {
+        const double ga[3] = {t.G[p][0][a], t.G[p][1][a], t.G[p][2][a]};
+        const double gb[3] = {t.G[p][0][b], t.G[p][1][b], t.G[p][2][b]};
+        o.c[p][a][b][0] = ga[0] * gb[0];
+        o.c[p][a][b][1] = ga[1] * gb[1];
+        o.c[p][a][b][2] = ga[2] * gb[2];
+        o.c[p][a][b][3] = ga[0] * gb[1] + ga[1] * gb[0];
+        o.c[p][a][b][4] = ga[0] * gb[2] + ga[2] * gb[0];
+        o.c[p][a][b][5] = ga[1] * gb[2] + ga[2] * gb[1];
+      }
+  return o;
+}
+__device__ const RefGP d_refGP = make_refGP();
+
+template <int AS, int OBS>
+__device__ inline void sweep_contract_p3(const double2 *__restrict__ rec, int myslot, double *acc) {
+#pragma unroll
+  for (int oy = -1; oy <= 0; oy++)
+#pragma unroll
+    for (int ox = -1; ox <= 0; ox++) {
+      const double2 *rp = rec + (myslot + ox + SW_SY * oy);
+      const int ia = hex_idx(-ox, -oy, AS);
+#pragma unroll
+      for (int p = 0; p < 8; p++) {
+        const double2 c0 = rp[(3 * p) * SW_NS], c1 = rp[(3 * p + 1) * SW_NS], c2 = rp[(3 * p + 2) * SW_NS];
+#pragma unroll
+        for (int by = 0; by <= 1; by++)
+#pragma unroll
+          for (int bx = 0; bx <= 1; bx++) {
+            const double *k = d_refGP.c[p][ia][hex_idx(bx, by, OBS)];
+            const int t = (oy + by + 1) * 3 + (ox + bx + 1);
+            double v = acc[t];
+            v = fma(k[0], c0.x, v);
+            v = fma(k[1], c0.y, v);
+            v = fma(k[2], c1.x, v);
+            v = fma(k[3], c1.y, v);
+            v = fma(k[4], c2.x, v);
+            v = fma(k[5], c2.y, v);
+            acc[t] = v;
+          }
+      }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_assemble_sweep_p3(const Slab s, const KArgs a) {
+  constexpr int KIND = KIND_POISSON, NACC = 9, NPAIR = 24, CH = 9;
+  static_assert(3 * 64 * CH * 8 <= NPAIR * SW_NS * 16, "staging aliases the record buffer");
+  __shared__ double2 sh_rec[NPAIR * SW_NS];  // 46 080 B: C_p of the 8 Gauss points, pair-SoA rec[3p + q][slot]
+  __shared__ double sh_x[2 * 108 * 3];       // node layers L, L+1 of the 18x6 halo'd tile
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int lx = lane & 15, r = lane >> 4, ly = ((r & 1) << 1) | (r >> 1);
+  const int64_t M = s.dim[0], N = s.dim[1];
+  const int64_t i0 = a.x0 + (int64_t)blockIdx.x * SW_TX, j0 = a.y0 + (int64_t)blockIdx.y * SW_TY;
+  const int64_t zc0 = a.s0 + (int64_t)blockIdx.z * SW_ZC;
+  const int64_t zc1 = (zc0 + SW_ZC < a.s1) ? zc0 + SW_ZC : a.s1;
+  const int nsteps = (int)(zc1 - zc0) + 1;
+  const int myslot = (lx + 1) + SW_SY * (ly + 1);
+  const int nvx = (a.x1 - i0 < SW_TX) ? (int)(a.x1 - i0) : SW_TX;
+  double *stage = reinterpret_cast<double *>(sh_rec) + ((w == 0) ? 0 : (w == 3 ? 1 : 2)) * (64 * CH);
+  double acc[NACC];
+
+  for (int st = 0; st < nsteps; st++) {
+    const int64_t L = zc0 - 1 + st;  // element layer of this step
+    for (int q = tid; q < 216; q += 256) {  // node coordinates of layers L, L+1 (clamped reads)
+      const int cz = q / 108, rem = q - 108 * cz, cy = rem / 18, cx = rem - 18 * cy;
+      int64_t gi = i0 - 1 + cx, gj = j0 - 1 + cy, gk = L + cz;
+      gi = gi < 0 ? 0 : (gi > M - 1 ? M - 1 : gi);
+      gj = gj < 0 ? 0 : (gj > N - 1 ? N - 1 : gj);
+      gk = gk < s.cks ? s.cks : (gk > a.cke - 1 ? a.cke - 1 : gk);
+      const int64_t node = gi + M * (gj + N * (gk - s.cks));
+#pragma unroll
+      for (int d = 0; d < 3; d++) sh_x[3 * q + d] = a.coords[3 * node + d];
+    }
+    __syncthreads();  // coordinates staged; the previous step's staged output has been read
+
+    // records: wave w builds Gauss points 2w and 2w+1 of every element slot
+#pragma unroll 1
+    for (int pp = 0; pp < 2; pp++) {
+      const int p = 2 * w + pp;
+      const double(*G)[8] = c_tab3.G[p];
+#pragma unroll 1
+      for (int e = lane; e < SW_NS; e += 64) {
+        const int ex = e % SW_SY, ey = e / SW_SY;
+        const int64_t gex = i0 - 1 + ex, gey = j0 - 1 + ey;
+        const bool eok = ex < SW_TX + 1 && gex >= 0 && gex < M - 1 && gey >= 0 && gey < N - 1 && L >= s.els && L < s.ele;
+        double2 *dst = sh_rec + (3 * p) * SW_NS + e;
+        if (!eok) {
+          dst[0] = dst[SW_NS] = dst[2 * SW_NS] = make_double2(0.0, 0.0);
+          continue;
+        }
+        double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+        for (int n = 0; n < 8; n++) {
+          const double *xn = sh_x + 3 * ((ex + HDI[n]) + 18 * ((ey + HDJ[n]) + 6 * HDK[n]));
+          const double x0 = xn[0], x1 = xn[1], x2 = xn[2];
+#pragma unroll
+          for (int rr = 0; rr < 3; rr++) {
+            J[rr][0] = J[rr][0] + G[rr][n] * x0;
+            J[rr][1] = J[rr][1] + G[rr][n] * x1;
+            J[rr][2] = J[rr][2] + G[rr][n] * x2;
+          }
+        }
+        double iJ[3][3];
+        const double t4 = J[2][0] * J[0][1], t6 = J[2][0] * J[0][2], t8 = J[1][0] * J[0][1];
+        const double t10 = J[1][0] * J[0][2], t12 = J[0][0] * J[1][1], t14 = J[0][0] * J[1][2];
+        const double t17 = 1.0 / (t4 * J[1][2] - t6 * J[1][1] - t8 * J[2][2] + t10 * J[2][1] + t12 * J[2][2] - t14 * J[2][1]);
+        iJ[0][0] = (J[1][1] * J[2][2] - J[1][2] * J[2][1]) * t17;
+        iJ[0][1] = -(J[0][1] * J[2][2] - J[0][2] * J[2][1]) * t17;
+        iJ[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * t17;
+        iJ[1][0] = -(-J[2][0] * J[1][2] + J[1][0] * J[2][2]) * t17;
+        iJ[1][1] = (-t6 + J[0][0] * J[2][2]) * t17;
+        iJ[1][2] = -(-t10 + t14) * t17;
+        iJ[2][0] = (-J[2][0] * J[1][1] + J[1][0] * J[2][1]) * t17;
+        iJ[2][1] = -(-t4 + J[0][0] * J[2][1]) * t17;
+        iJ[2][2] = (-t8 + t12) * t17;
+        const double det = J[0][0] * J[1][1] * J[2][2] - J[0][0] * J[1][2] * J[2][1] - J[1][0] * J[0][1] * J[2][2] +
+                           J[1][0] * J[0][2] * J[2][1] + J[2][0] * J[0][1] * J[1][2] - J[2][0] * J[0][2] * J[1][1];
+        const double wJ = 1.0 * det;
+        if (!(wJ > 0.0)) atomicAdd(a.bad, 1ULL);
+        double Cm[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+          for (int l = k; l < 3; l++) Cm[k][l] = (iJ[0][k] * iJ[0][l] + iJ[1][k] * iJ[1][l] + iJ[2][k] * iJ[2][l]) * wJ;
+        dst[0] = make_double2(Cm[0][0], Cm[1][1]);
+        dst[SW_NS] = make_double2(Cm[2][2], Cm[0][1]);
+        dst[2 * SW_NS] = make_double2(Cm[0][2], Cm[1][2]);
+      }
+    }
+    __syncthreads();
+
+    int role;
+    if (w == 0) role = 0;
+    else if (w == 3) role = 3;
+    else role = ((st + w) & 1) ? 1 : 2;
+    const int64_t kn = (role < 2) ? L + 1 : L;
+    const bool active = (role < 2) ? (kn < zc1) : (kn >= zc0);
+    if (role != 2) {
+#pragma unroll
+      for (int q = 0; q < NACC; q++) acc[q] = 0.0;
+    }
+    if (active) {
+      if (role == 0)      sweep_contract_p3<1, 0>(sh_rec, myslot, acc);
+      else if (role == 1) sweep_contract_p3<1, 1>(sh_rec, myslot, acc);
+      else if (role == 2) sweep_contract_p3<0, 0>(sh_rec, myslot, acc);
+      else                sweep_contract_p3<0, 1>(sh_rec, myslot, acc);
+    }
+    __syncthreads();  // every wave has read its records: the staging areas alias them
+    if (active && role != 1)
+      sweep_store_third<KIND>(s, a, acc, stage, lane, i0, j0, kn, (role == 0) ? -1 : (role == 2 ? 0 : 1), nvx);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Affine fast path.  When an element is a parallelepiped (its twelve edges are three exactly equal
 // quadruples -- true for every element of DMDASetUniformCoordinates meshes, P3:663, S3:1198) the Jacobian
 // is the same at all Gauss points, so with Gauss-point-constant material
