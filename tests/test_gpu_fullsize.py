@@ -140,3 +140,23 @@ def test_poisson3d_256_and_elastic2d_2048_properties(env):
     bh = b.cpu().numpy().reshape(M, M, 2)
     assert (bh[:, 0, 0] == 1.0).all() and (bh[:, -1, 0] == -1.0).all() and not bh[:, 1:-1].any()
     plan.close()
+
+
+def test_bench_two_ranks_end_to_end():
+    """The N > 1 path of bench.py as the driver launches it (torch.distributed.run, one rank per process), rehearsed
+    with two ranks sharing this one GPU over gloo: split interface call, non-blocking exchange, assembly, apply."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
+           "--share-gpu", "--no-cpu-baseline", "--steps", "2", "--warmup", "1", "--nel", "24"]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["global_elements"] == 2 * 24 ** 3
+    assert d["roofline"]["kernel_level"] == 2
