@@ -164,6 +164,15 @@ int femasm_interface_apply(femasm_plan *plan, const femasm_bc *bc, double *csr_v
 int femasm_compress_bc_rows(femasm_plan *plan, const femasm_bc *bc, const double *csr_values,
                             int64_t *rowptr_out, int32_t *colidx_out, double *values_out, int64_t *nnz_out);
 
+/* A11 in its general form, for Dirichlet sets other than the three built-in kinds: what
+ * MatZeroRows(A, n, rows, 1.0, NULL, NULL) + VecSetValues(b, n, rows, vals, INSERT_VALUES) do (S3:1497-1512,
+ * E2:741-875): every listed GLOBAL row becomes the unit row (its slots stay in the pattern as explicit zeros) and
+ * b[row] = vals[i] (0 if vals is NULL).  Rows of other slabs are ignored; a row listed twice takes one of its values
+ * (the drivers list edge nodes several times with the same value).  rows/vals: HOST or DEVICE; csr_values and b:
+ * DEVICE, either may be NULL.  Assemble with FEMASM_BC_NONE first. */
+int femasm_zero_rows(femasm_plan *plan, int64_t n, const int64_t *rows, const double *vals, double *csr_values,
+                     double *b);
+
 /* y = K x without forming K, from the same element arithmetic (any hexahedra / quads,
  * (E,nu) per Gauss point), Dirichlet rows as in the assembled matrix (row = diag * e_row, no column
  * elimination).  x: DEVICE vector on the node layers [cks,cke) of the plan's coordinate array; y: DEVICE, the

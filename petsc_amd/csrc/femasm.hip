@@ -1173,4 +1173,43 @@ int femasm_rigid_body_modes(femasm_plan *p, const double mom[10], double *modes)
   return FEMASM_OK;
 }
 
+int femasm_zero_rows(femasm_plan *p, int64_t n, const int64_t *rows, const double *vals, double *csr_values,
+                     double *b) {
+  if (!p || (n > 0 && !rows)) return fail(FEMASM_ERR_ARG, "null argument");
+  if (n <= 0 || (!csr_values && !b)) return FEMASM_OK;
+  HIPCHK(hipSetDevice(p->device));
+  if ((csr_values && !is_device_ptr(csr_values)) || (b && !is_device_ptr(b)))
+    return fail(FEMASM_ERR_ARG, "femasm_zero_rows works on device-resident csr_values / b");
+  const Slab &s = p->s;
+  const int64_t plane = (s.nsd == 3) ? s.dim[0] * s.dim[1] : s.dim[0];
+  const int64_t row0 = plane * s.ks * s.dof;
+  // the list (and the values) may live on the host: stage them
+  int64_t *d_rows = const_cast<int64_t *>(rows);
+  double *d_vals = const_cast<double *>(vals);
+  bool own_rows = false, own_vals = false;
+  if (!is_device_ptr(rows)) {
+    HIPCHK(hipMalloc(&d_rows, n * sizeof(int64_t)));
+    own_rows = true;
+    HIPCHK(hipMemcpyAsync(d_rows, rows, n * sizeof(int64_t), hipMemcpyHostToDevice, p->stream));
+  }
+  hipError_t e = hipSuccess;
+  if (vals && !is_device_ptr(vals)) {
+    e = hipMalloc(&d_vals, n * sizeof(double));
+    if (e == hipSuccess) {
+      own_vals = true;
+      e = hipMemcpyAsync(d_vals, vals, n * sizeof(double), hipMemcpyHostToDevice, p->stream);
+    }
+  }
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_zero_rows, dim3(nblk(n, 4)), dim3(256), 0, p->stream, n, d_rows, d_vals, row0, p->nrows,
+                       p->rowptr, p->colidx, csr_values, b);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+  if (own_rows) (void)hipFree(d_rows);
+  if (own_vals) (void)hipFree(d_vals);
+  if (e != hipSuccess) return fail(FEMASM_ERR_HIP, "femasm_zero_rows: %s", hipGetErrorString(e));
+  return FEMASM_OK;
+}
+
 }  // extern "C"

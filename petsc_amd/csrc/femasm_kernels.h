@@ -1738,4 +1738,21 @@ __global__ __launch_bounds__(256) void k_rigid_modes(const Slab s, const double 
     }
 }
 
+// ---------------------------------------------------------------------------
+// A11 in its general form: MatZeroRows(A, n, rows, 1.0, NULL, NULL) + VecSetValues(b, n, rows, vals, INSERT_VALUES)
+// for a caller-supplied list of GLOBAL rows (rows owned by other slabs are skipped).  One wave per listed row.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_zero_rows(int64_t n, const int64_t *rows, const double *vals, int64_t row0,
+                                                   int64_t nrows, const int64_t *rowptr, const int32_t *colidx,
+                                                   double *csr, double *b) {
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= n) return;
+  const int64_t g = rows[q], r = g - row0;
+  if (r < 0 || r >= nrows) return;
+  const int lane = threadIdx.x & 63;
+  if (csr)
+    for (int64_t t = rowptr[r] + lane; t < rowptr[r + 1]; t += 64) csr[t] = (colidx[t] == g) ? 1.0 : 0.0;
+  if (b && lane == 0) b[r] = vals ? vals[q] : 0.0;
+}
+
 }  // namespace femasm

@@ -31,7 +31,7 @@ EXPORTS = [
     "femasm_pattern_copy", "femasm_scatter_map", "femasm_assemble_system", "femasm_interface_buffers",
     "femasm_interface_set_buffers", "femasm_interface_apply", "femasm_compress_bc_rows", "femasm_plan_sync", "femasm_last_error",
     "femasm_version", "femasm_plan_set_fast_path", "femasm_plan_get_fast_path", "femasm_assemble_interface", "femasm_error_integrals", "femasm_fill_properties", "femasm_apply_operator",
-    "femasm_coo_indices", "femasm_coord_moments", "femasm_rigid_body_modes",
+    "femasm_coo_indices", "femasm_coord_moments", "femasm_rigid_body_modes", "femasm_zero_rows",
 ]
 
 
@@ -244,6 +244,11 @@ class Plan:
         """Orthonormal rigid-body modes (6 x nrows, 3 x nrows in 2-D) from the GLOBAL moments."""
         mom = (C.c_double * 10)(*[float(v) for v in moments])
         _check(load().femasm_rigid_body_modes(self._h, mom, _ptr(out)))
+
+    def zero_rows(self, rows, vals, values, b):
+        """MatZeroRows(diag 1) + VecSetValues for a list of global rows (int64 array/tensor, host or device)."""
+        n = len(rows) if isinstance(rows, np.ndarray) else rows.numel()
+        _check(load().femasm_zero_rows(self._h, C.c_int64(n), _ptr(rows), _ptr(vals), _ptr(values), _ptr(b)))
 
     def compress_bc_rows(self, values, bc):
         """PETSc's truncated MatZeroRows storage; host numpy in, host numpy out."""

@@ -729,3 +729,39 @@ def test_elastic_uniform_material_rhs_is_the_dirichlet_data(env):
     plan.assemble_system(None, b, material=None, E=90.0, nu=0.28, bc=F.BC_S3_ALLFACES_EXACT)
     assert np.abs(b.cpu().numpy() - bref).max() <= 1e-15
     plan.close()
+
+
+@pytest.mark.parametrize("host_list", [False, True])
+def test_zero_rows_list_reproduces_the_builtin_dirichlet_kinds(env, host_list):
+    """femasm_zero_rows on a BC_NONE assembly with the list of Dirichlet rows and their values = the built-in
+    S3 all-faces kind (MatZeroRows + VecSetValues semantics), on one GPU and per slab (foreign rows skipped)."""
+    torch, F, dev, slab, O = env["torch"], env["F"], env["dev"], env["slab"], env["O"]
+    case = make_case(env, "s3", (6, 5, 7), vary_material=True)
+    M, N, P = case["dims"]
+    flags = O.bc_flags("s3", M, N, P).astype(bool)
+    rows = np.nonzero(flags)[0].astype(np.int64)
+    rows = np.concatenate([rows, rows[:7]])  # duplicates, as the drivers' face loops produce on edges
+    vals = case["b"][rows].copy()            # after the oracle's BC step b holds the Dirichlet values there
+    for ks, ke in [(0, P)] + list(slab.slab_ranges(P, 2)):
+        cks, cke, els = max(ks - 1, 0), min(ke + 1, P), max(ks - 1, 0)
+        cl = case["coords"].reshape(P, -1)[cks:cke].reshape(-1)
+        ml = case["props"].reshape(P - 1, -1)[els:ke - 1].reshape(-1)
+        outs = []
+        for kind in ("list", "builtin"):
+            plan = F.Plan(F.ELASTIC3D_Q1, M, N, P, coords=torch.from_numpy(cl).to(dev), ks=ks, ke=ke, cks=cks, cke=cke)
+            v = torch.empty(plan.nnz, dtype=torch.float64, device=dev)
+            b = torch.empty(plan.nrows, dtype=torch.float64, device=dev)
+            mat = torch.from_numpy(ml).to(dev)
+            if kind == "builtin":
+                plan.assemble_system(v, b, material=mat, stride=400, bc=F.BC_S3_ALLFACES_EXACT, e_ks=els)
+            else:
+                plan.assemble_system(v, b, material=mat, stride=400, bc=F.BC_NONE, e_ks=els)
+                r_, v_ = (rows, vals) if host_list else (torch.from_numpy(rows).to(dev), torch.from_numpy(vals).to(dev))
+                plan.zero_rows(r_, v_, v, b)
+            outs.append((v.cpu().numpy(), b.cpu().numpy()))
+            plan.close()
+        # the top layer of a lower slab is partial in both (same partial sums); Dirichlet rows identical
+        assert rel(outs[0][0], outs[1][0]) <= TOL and rel(outs[0][1], outs[1][1]) <= TOL
+        lo, hi = 3 * M * N * ks, 3 * M * N * ke
+        own = flags[lo:hi]
+        assert np.array_equal(outs[0][1][own], case["b"][lo:hi][own])
