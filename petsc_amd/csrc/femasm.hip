@@ -341,6 +341,7 @@ int launch_rhs(femasm_plan *p, const femasm_material *mat, int bc, double *out, 
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu[0], k_rhs_elem_elastic_runs<false>, 64, 0));
         if (wg_per_cu[0] < 1) wg_per_cu[0] = 1;
         if (wg_per_cu[1] < 1) wg_per_cu[1] = 1;
+        if (getenv("FEMASM_DEBUG")) fprintf(stderr, "[femasm] rhs runs: ncu %d, workgroups per CU %d (general) %d (rect)\n", ncu, wg_per_cu[0], wg_per_cu[1]);
       }
       auto grid = [&](int v) { const int64_t r = (int64_t)ncu * wg_per_cu[v]; return dim3((unsigned)(ntasks < r ? ntasks : r)); };
       if (a.rect) hipLaunchKernelGGL(k_rhs_elem_elastic_runs<true>, grid(1), dim3(64), 0, p->stream, sl, a);

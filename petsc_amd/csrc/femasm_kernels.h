@@ -18,13 +18,14 @@
 //    reference's element order (k->j->i).
 #pragma once
 #include "femasm_device.h"
+#include <type_traits>
 // Profiling builds (never shipped: the build of __graft_entry__ does not define it).  -DFEMASM_EXP=n removes one
 // phase of a kernel so that its cost can be read off a timing (DESIGN.md section 3 quotes these):
 //   1  the global stores of the stiffness kernels (values are consumed by an empty asm)
 //   2  the contraction of the general kernels / direct lane-wise stores instead of the LDS transposition
 //   3  the geometry phase of the general kernels; in the row-sweep and RHS kernels: per-phase cycle counters
 //      (PH_* macros, dumped by femasm_plan_destroy)
-//   7  the record stores of k_rhs_elem_elastic_runs
+//   7  the record stores of k_rhs_elem_elastic_runs;  8  also its arithmetic (input stream + LDS commit only)
 #ifndef FEMASM_EXP
 #define FEMASM_EXP 0
 #endif
@@ -817,8 +818,13 @@ __global__ __launch_bounds__(64) void k_rhs_elem_elastic_runs(const Slab s, cons
   for (int k = 0; k < 18; k++) pin[k] = make_double2(0.0, 0.0);
 #pragma unroll
   for (int d = 0; d < (RECT ? 1 : 3); d++) pxc[d] = 0.0;
-  // step (task t, layer l of its chunk, half h): elements 8h .. 8h+7 of the run -> registers (clamped, never masked)
-  auto request = [&](int64_t t, int l, int h, double2 *pin, double *pxc) {
+  // step (task t, layer l of its chunk, half h): elements 8h .. 8h+7 of the run -> registers (clamped, never masked).
+  // COMMIT: each register is first written to LDS (the step that was requested before) and re-requested at once, so
+  // the wave keeps its 19 loads in flight instead of draining them all, committing, and only then asking again
+  // (measured: the input stream alone 0.82 -> see DESIGN 4.5).
+  auto request = [&](auto commit, int64_t t, int l, int h, double2 *pin, double *pxc) {
+    constexpr bool COMMIT = decltype(commit)::value;
+    double2 *dstq = reinterpret_cast<double2 *>(sh_in);
     if (t >= ntasks) { t = ntasks - 1; l = 0; h = 0; }
     const uint32_t t32 = (uint32_t)t, tt = t32 / nr, r = t32 - tt * nr, ch = tt / (uint32_t)my, ey = tt - ch * (uint32_t)my;
     const int64_t ex0 = 16 * (int64_t)r, ezr = (int64_t)ch * ZC + l;  // element layer relative to els
@@ -829,13 +835,25 @@ __global__ __launch_bounds__(64) void k_rhs_elem_elastic_runs(const Slab s, cons
     for (int k = 0; k < 18; k++) {
       const int c = 64 * k + lane, xe = c / 144, rr = c - 144 * xe;
       const int xo = (8 * h + xe < nx) ? 8 * h + xe : nx - 1;
+      if constexpr (COMMIT) dstq[xe * (S / 2) + rr] = pin[k];
       // streamed once: non-temporal (6.2 -> 7.0 TB/s on the bare read pattern, scripts/ubench/read_pattern.hip)
       typedef double d2v __attribute__((ext_vector_type(2)));
       const d2v v = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(blk) + (xo * st2 + rr));
       pin[k] = make_double2(v.x, v.y);
+      // keep the issue order identical at every call site: the waits are counted in issue order, and a different
+      // order in the prologue makes the compiler drain all loads before the first commit
+      asm volatile("" ::: "memory");
     }
     const int xo = (8 * h + x < nx) ? 8 * h + x : nx - 1;
     const double *cn = a.coords + 3 * (ex0 + xo + M * (ey + N * (s.els + ezr - s.cks))) + cofs;
+    if constexpr (COMMIT) {
+      if constexpr (RECT) {
+        sh_xc[x][j] = pxc[0];
+      } else {
+#pragma unroll
+        for (int d = 0; d < 3; d++) sh_xc[x][3 * j + d] = pxc[d];
+      }
+    }
     pxc[0] = cn[0];
     if constexpr (!RECT) {
       pxc[1] = cn[1];
@@ -844,7 +862,7 @@ __global__ __launch_bounds__(64) void k_rhs_elem_elastic_runs(const Slab s, cons
   };
 
   int64_t t = blockIdx.x;
-  request(t, 0, 0, pin, pxc);
+  request(std::false_type{}, t, 0, 0, pin, pxc);
   for (; t < ntasks; t += gridDim.x) {
     const uint32_t t32 = (uint32_t)t, tt = t32 / nr, r = t32 - tt * nr, ch = tt / (uint32_t)my;
     const int nx = (int)((mx - 16 * (int64_t)r < 16) ? mx - 16 * (int64_t)r : 16);
@@ -860,7 +878,7 @@ __global__ __launch_bounds__(64) void k_rhs_elem_elastic_runs(const Slab s, cons
           for (int c = 0; c < 3; c++) sh_o[(c * 2 + dy) * 20 + 16] = o16[c];
       }
       wave_sync();
-#if FEMASM_EXP == 7
+#if FEMASM_EXP == 7 || FEMASM_EXP == 8
       if (sh_o[0] == 123.456)
 #endif
       {
@@ -875,29 +893,25 @@ __global__ __launch_bounds__(64) void k_rhs_elem_elastic_runs(const Slab s, cons
     for (int l = 0; l < nlz; l++) {
 #pragma unroll 1
       for (int h = 0; h < 2; h++) {
-        {
-          double2 *dst = reinterpret_cast<double2 *>(sh_in);
-#pragma unroll
-          for (int k = 0; k < 18; k++) {
-            const int c = 64 * k + lane, xe = c / 144, rr = c - 144 * xe;
-            dst[xe * (S / 2) + rr] = pin[k];
-          }
-          if constexpr (RECT) {
-            sh_xc[x][j] = pxc[0];
-          } else {
-#pragma unroll
-            for (int d = 0; d < 3; d++) sh_xc[x][3 * j + d] = pxc[d];
-          }
-        }
-        {  // the step after this one
+        {  // commit this step's inputs while asking for those of the step after it
           int64_t tn = t;
           int ln = l, hn = h + 1;
           if (hn == 2) { hn = 0; ln = l + 1; }
           if (ln == nlz) { ln = 0; tn = t + gridDim.x; }
-          request(tn, ln, hn, pin, pxc);
+          request(std::true_type{}, tn, ln, hn, pin, pxc);
         }
         wave_sync();
         const double *in = sh_in + x * S;
+#if FEMASM_EXP == 8  // skeleton: input stream + commit only
+        {
+          const double vv = in[j] + sh_xc[x][j & 3];
+          wave_sync();
+#pragma unroll
+          for (int c = 0; c < 3; c++) sh_o[((8 * h + x) * 8 + j) * 3 + c] = vv;
+          wave_sync();
+          continue;
+        }
+#endif
         double dx, dyy, dzz;
         if constexpr (RECT) {
           const double2 cx = *reinterpret_cast<const double2 *>(&sh_xc[x][0]);

@@ -132,6 +132,98 @@ __global__ __launch_bounds__(256) void wr_only(double *out, int64_t ngroups) {
 #pragma unroll
     for (int k = 0; k < 3; k++) *reinterpret_cast<double2 *>(out + g * 384 + (lane + 64 * k) * 2) = acc;
 }
+// the RHS runs kernel's input side alone: one wave per workgroup, WPC per CU, 8 consecutive elements per step as 18
+// non-temporal 16-byte loads per lane, one step ahead; LDS = 1: commit to LDS (padded layout) and read one value back
+template <int LDS>
+__global__ __launch_bounds__(64) void runs_like(const double *gp, int64_t nel, double *sink) {
+  __shared__ double2 sh[8 * 148];
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x;
+  double2 pin[18];
+  double acc = 0.0;
+  auto req = [&](int64_t e0) {
+    if (e0 > nel - 8) e0 = nel - 8;
+    const d2v *blk = reinterpret_cast<const d2v *>(gp + e0 * 400 + 112);
+#pragma unroll
+    for (int k = 0; k < 18; k++) {
+      const int c = 64 * k + lane, xe = c / 144, rr = c - 144 * xe;
+      const d2v v = __builtin_nontemporal_load(blk + (xe * 200 + rr));
+      pin[k] = make_double2(v.x, v.y);
+      asm volatile("" ::: "memory");
+    }
+  };
+  const int64_t nstep = nel / 8;
+  int64_t st = blockIdx.x;
+  req(8 * st);
+  for (; st < nstep; st += gridDim.x) {
+    if (LDS) {
+#pragma unroll
+      for (int k = 0; k < 18; k++) {
+        const int c = 64 * k + lane, xe = c / 144, rr = c - 144 * xe;
+        sh[xe * 148 + rr] = pin[k];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 18; k++) acc += pin[k].x + pin[k].y;
+    }
+    req(8 * (st + gridDim.x));
+    if (LDS) {
+      __builtin_amdgcn_wave_barrier();
+      acc += sh[(lane >> 3) * 148 + (lane & 7)].x;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (acc == 123.456) sink[0] = acc;
+}
+// the same with the runs kernel's traversal: task = (chunk of ZC element layers, row, run of 16 elements), a wave
+// walks its run through the chunk's layers (two 8-element steps per layer); COORD = 1 adds the per-step coordinate load
+template <int ZC, int COORD>
+__global__ __launch_bounds__(64) void runs_trav(const double *gp, const double *coords, int mx, int my, int mz, double *sink) {
+  __shared__ double2 sh[8 * 148];
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x;
+  double2 pin[18];
+  double pxc = 0.0, acc = 0.0;
+  const uint32_t nr = (mx + 15) / 16, nzc = (mz + ZC - 1) / ZC;
+  const int64_t ntasks = (int64_t)nzc * my * nr;
+  auto req = [&](int64_t t, int l, int h) {
+    if (t >= ntasks) { t = ntasks - 1; l = 0; h = 0; }
+    const uint32_t t32 = (uint32_t)t, tt = t32 / nr, r = t32 - tt * nr, ch = tt / (uint32_t)my, ey = tt - ch * (uint32_t)my;
+    const int64_t e0 = 16 * (int64_t)r + 8 * h + (int64_t)mx * (ey + (int64_t)my * (ch * ZC + l));
+    const d2v *blk = reinterpret_cast<const d2v *>(gp + e0 * 400 + 112);
+#pragma unroll
+    for (int k = 0; k < 18; k++) {
+      const int c = 64 * k + lane, xe = c / 144, rr = c - 144 * xe;
+      const d2v v = __builtin_nontemporal_load(blk + (xe * 200 + rr));
+      pin[k] = make_double2(v.x, v.y);
+      asm volatile("" ::: "memory");
+    }
+    if (COORD) pxc = coords[3 * ((16 * r + 8 * h + (lane >> 3)) + (int64_t)(mx + 1) * (ey + (int64_t)(my + 1) * (ch * ZC + l))) + (lane & 1)];
+  };
+  int64_t t = blockIdx.x;
+  req(t, 0, 0);
+  for (; t < ntasks; t += gridDim.x) {
+    const uint32_t ch = (uint32_t)t / nr / (uint32_t)my;
+    const int nlz = (mz - (int)ch * ZC < ZC) ? mz - (int)ch * ZC : ZC;
+    for (int l = 0; l < nlz; l++)
+      for (int h = 0; h < 2; h++) {
+#pragma unroll
+        for (int k = 0; k < 18; k++) {
+          const int c = 64 * k + lane, xe = c / 144, rr = c - 144 * xe;
+          sh[xe * 148 + rr] = pin[k];
+        }
+        acc += pxc;
+        int64_t tn = t; int ln = l, hn = h + 1;
+        if (hn == 2) { hn = 0; ln = l + 1; }
+        if (ln == nlz) { ln = 0; tn = t + gridDim.x; }
+        req(tn, ln, hn);
+        __builtin_amdgcn_wave_barrier();
+        acc += sh[(lane >> 3) * 148 + (lane & 7)].x;
+        __builtin_amdgcn_wave_barrier();
+      }
+  }
+  if (acc == 123.456) sink[0] = acc;
+}
 // plain linear read
 __global__ void lin(const double2 *p, int64_t n2, double *sink) {
   double2 acc = make_double2(0, 0);
@@ -156,6 +248,19 @@ int main() {
   double *outb; hipMalloc(&outb, (size_t)24 * 2097152 * 8 + 4096);
   hipMemset(gp, 0x3f, nel * 400 * 8);  // non-zero bytes
   const double b288 = nel * 288.0 * 8, b400 = nel * 400.0 * 8;
+  for (int wpc : {7, 10, 14}) {
+    printf("--- runs-like, %d one-wave workgroups per CU ---\n", wpc);
+    timeit("18 NT loads/lane one step ahead, registers only", b288, [&] { runs_like<0><<<256 * wpc, 64>>>(gp, nel, sink); });
+    timeit("the same + LDS commit", b288, [&] { runs_like<1><<<256 * wpc, 64>>>(gp, nel, sink); });
+  }
+  {
+    double *co; hipMalloc(&co, (size_t)129 * 129 * 129 * 3 * 8); hipMemset(co, 0, (size_t)129 * 129 * 129 * 3 * 8);
+    printf("--- runs traversal (128^3 elements), 7 one-wave workgroups per CU ---\n");
+    timeit("chunks of 32 layers", b288, [&] { runs_trav<32, 0><<<256 * 7, 64>>>(gp, co, 128, 128, 128, sink); });
+    timeit("chunks of 32 layers + coordinate load", b288, [&] { runs_trav<32, 1><<<256 * 7, 64>>>(gp, co, 128, 128, 128, sink); });
+    timeit("chunks of 16 layers", b288, [&] { runs_trav<16, 0><<<256 * 7, 64>>>(gp, co, 128, 128, 128, sink); });
+    timeit("chunks of 8 layers", b288, [&] { runs_trav<8, 0><<<256 * 7, 64>>>(gp, co, 128, 128, 128, sink); });
+  }
   for (int wg : {3, 8}) {
     printf("--- %d WG/CU ---\n", wg);
     timeit("linear 16B/lane, whole array", b400, [&] { lin<<<256 * wg, 256>>>((const double2 *)gp, nel * 200, sink); });
