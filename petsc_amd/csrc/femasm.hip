@@ -201,7 +201,8 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
     const bool shell_is_bc = (bc == FEMASM_BC_POISSON_INLOOP || bc == FEMASM_BC_S3_ALLFACES_EXACT);
     if (shell_is_bc) {  // Dirichlet rows of the boundary shell
       const KArgs a = make_kargs<KIND>(p, mat, bc, out, Box{0, M, 0, N, s0, s1}, s0, iface);
-      hipLaunchKernelGGL(k_bc_rows, dim3(1, (unsigned)N, (unsigned)(s1 - s0)), dim3(256), 0, p->stream, p->s, a);
+      const int64_t nrow = N * (s1 - s0);
+      hipLaunchKernelGGL(k_bc_rows, dim3((unsigned)(nrow < 8192 ? nrow : 8192)), dim3(256), 0, p->stream, p->s, a);
       HIPCHK(hipGetLastError());
     }
     // interior nodes (full 27-neighbour stencil): z-sweep kernel

@@ -1366,8 +1366,12 @@ __global__ __launch_bounds__(64) void k_assemble_e2_rect(const Slab s, const KAr
 __global__ __launch_bounds__(256) void k_bc_rows(const Slab s, const KArgs a) {
   const int64_t M = s.dim[0], N = s.dim[1];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // x-rows of nodes (j, k) are walked with a stride (most rows have two Dirichlet nodes only); S3 128^3: 45 us =
+  // 4 TB/s of stores; P3 256^3: 100 us -- one wave per 144-byte row is instruction-bound there
+  const int64_t nrow = (s.nsd == 3) ? N * (a.s1 - a.s0) : (a.s1 - a.s0);
+  for (int64_t row = blockIdx.x; row < nrow; row += gridDim.x) {
   int64_t j, k;
-  if (s.nsd == 3) { j = blockIdx.y; k = a.s0 + blockIdx.z; } else { j = a.s0 + blockIdx.y; k = 0; }
+  if (s.nsd == 3) { j = row % N; k = a.s0 + row / N; } else { j = a.s0 + row; k = 0; }
   const bool full = (M < 3) || is_bc_node(s, a.bc, 1, j, k);  // is an x-interior node of this row Dirichlet?
   const int64_t istep = full ? 4 : M;
   for (int64_t i = full ? w : (w == 0 ? 0 : ((w == 1 && M > 1) ? M - 1 : M)); i < M; i += istep) {
@@ -1389,6 +1393,7 @@ __global__ __launch_bounds__(256) void k_bc_rows(const Slab s, const KArgs a) {
       blk[t] = (r == self + c) ? diag : 0.0;
       r += 64;
     }
+  }
   }
 }
 
