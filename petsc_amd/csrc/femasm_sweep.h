@@ -1373,8 +1373,11 @@ __global__ __launch_bounds__(256) void k_bc_rows(const Slab s, const KArgs a) {
   int64_t j, k;
   if (s.nsd == 3) { j = row % N; k = a.s0 + row / N; } else { j = a.s0 + row; k = 0; }
   const bool full = (M < 3) || is_bc_node(s, a.bc, 1, j, k);  // is an x-interior node of this row Dirichlet?
-  const int64_t istep = full ? 4 : M;
-  for (int64_t i = full ? w : (w == 0 ? 0 : ((w == 1 && M > 1) ? M - 1 : M)); i < M; i += istep) {
+  // dof 1 (27 values per node): each half-wave takes a node of its own; otherwise one wave per node
+  const int sub = (s.dof == 1) ? (lane >> 5) : 0, lw = (s.dof == 1) ? 32 : 64, ll = lane & (lw - 1);
+  const int slot = (s.dof == 1) ? 2 * w + sub : w, nslot = (s.dof == 1) ? 8 : 4;
+  const int64_t istep = full ? nslot : M;
+  for (int64_t i = full ? slot : (slot == 0 ? 0 : ((slot == 1 && M > 1) ? M - 1 : M)); i < M; i += istep) {
     if (!is_bc_node(s, a.bc, i, j, k)) continue;
     double diag = a.iface ? 0.0 : 1.0;
     if (a.bc == BC_POISSON) {
@@ -1387,11 +1390,11 @@ __global__ __launch_bounds__(256) void k_bc_rows(const Slab s, const KArgs a) {
     // position of the node itself among its neighbours
     const int self = (((s.nsd == 3 ? (k > 0) : 0) * cy + (j > 0)) * cx + (i > 0)) * s.dof;
     double *blk = a.out + (row_start(s, i, j, k, 0) - a.base_off);
-    int c = 0, r = lane;  // value t = c * cnt + r of the node's block
-    for (int t = lane; t < s.dof * cnt; t += 64) {
+    int c = 0, r = ll;  // value t = c * cnt + r of the node's block
+    for (int t = ll; t < s.dof * cnt; t += lw) {
       while (r >= cnt) { r -= cnt; c++; }
       blk[t] = (r == self + c) ? diag : 0.0;
-      r += 64;
+      r += lw;
     }
   }
   }
