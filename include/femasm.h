@@ -153,7 +153,10 @@ int femasm_interface_set_buffers(femasm_plan *plan, double *send_buf, double *re
 /* Optional first half of a split call, for overlapping the exchange with the bulk of the work: computes ONLY
  * the partial rows owed to the rank below (the send buffer) and returns without waiting, so that the caller can
  * start its send on the plan's stream and then call femasm_assemble_system, which skips that part once.  Device
- * material pointers only.  No counterpart in the reference (MatAssemblyBegin/End P3:345-346 is the closest). */
+ * material pointers only.  Nothing is read back here: the buffer is final in stream order whatever the mesh (the
+ * general kernels are queued behind the fast ones and run only if the fast kernels' premise failed), and geometry
+ * errors (det J <= 0) are reported by the femasm_assemble_system call that must follow on the same inputs.
+ * No counterpart in the reference (MatAssemblyBegin/End P3:345-346 is the closest). */
 int femasm_assemble_interface(femasm_plan *plan, const femasm_material *material, const femasm_bc *bc);
 /* own + received, fixed order (deterministic); Dirichlet rows are left untouched. */
 int femasm_interface_apply(femasm_plan *plan, const femasm_bc *bc, double *csr_values, double *b);

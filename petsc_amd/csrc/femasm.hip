@@ -90,6 +90,8 @@ struct femasm_plan {
   int ncu = 256;                       // compute units of the device
   int rhs_wg_per_cu[2] = {0, 0};       // resident workgroups per CU of k_rhs_elem_elastic_runs<false / true>
   bool rect_checked = false;           // k_check_rectilinear ran on the stream in this call (its verdict is bad[3])
+  bool cond_general = false;           // launch_K: the general kernels are launched with KArgs::cond set
+  bool iface_rect = false;             // femasm_assemble_interface ran the rectilinearity check: its verdict carries over
   bool iface_done = false;             // femasm_assemble_interface already filled the send buffer for the next call
   bool time_main = false;              // record ev[4], ev[5] around the dominant K kernel of the main pass
   double bytes_main = 0.0;             // its algorithmic bytes
@@ -138,6 +140,7 @@ KArgs make_kargs(femasm_plan *p, const femasm_material *mat, int bc, double *out
   a.mat_stride = mat ? mat->stride : 0;
   a.bc = bc;
   a.iface = iface;
+  a.cond = p->cond_general ? 1 : 0;
   return a;
 }
 
@@ -631,10 +634,18 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
   }
   ms_staging += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
-  HIPCHK(hipMemsetAsync(p->bad, 0, 4 * sizeof(unsigned long long), p->stream));
-
-  int rc = launch_rect_check(p);
-  if (rc) return rc;
+  int rc = 0;
+  if (p->iface_done) {
+    // femasm_assemble_interface ran just before on the same inputs without reading its flags back: they carry
+    // over (a broken premise or a timed-out hand-shake there is found here), and so does the verdict of its
+    // rectilinearity check; the count of bad Gauss points starts again (this call integrates those elements too)
+    HIPCHK(hipMemsetAsync(p->bad, 0, sizeof(unsigned long long), p->stream));
+    p->rect_checked = p->iface_rect && p->fast_level == 2;
+  } else {
+    HIPCHK(hipMemsetAsync(p->bad, 0, 4 * sizeof(unsigned long long), p->stream));
+    rc = launch_rect_check(p);
+    if (rc) return rc;
+  }
   // ---- K ----
   auto run_K = [&]() -> int {
     int r = 0;
@@ -786,31 +797,39 @@ int femasm_assemble_interface(femasm_plan *p, const femasm_material *mat, const 
     mloc.layout = FEMASM_MAT_UNIFORM;
   }
   const Slab &s = p->s;
-  if (s.ks == 0) { p->iface_done = true; return FEMASM_OK; }  // lowest slab: nothing is owed
+  if (s.ks == 0) { p->iface_done = false; return FEMASM_OK; }  // lowest slab: nothing is owed, nothing carries over
   if (!p->send) return fail(FEMASM_ERR_ARG, "no send buffer");
   p->time_main = false;
   int rc = 0;
-  unsigned long long flags[3] = {0, 0, 0};
-  for (int attempt = 0; attempt < 3; attempt++) {
-    p->used_fast = false;
-    HIPCHK(hipMemsetAsync(p->bad, 0, 4 * sizeof(unsigned long long), p->stream));
-    rc = launch_rect_check(p);
-    if (rc) return rc;
+  auto layer_K = [&]() -> int {
     switch (p->kind) {
-      case KIND_POISSON: rc = launch_K<KIND_POISSON>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1); break;
-      case KIND_PLANE:   rc = launch_K<KIND_PLANE>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1); break;
-      case KIND_ELASTIC: rc = launch_K<KIND_ELASTIC>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1); break;
+      case KIND_POISSON: return launch_K<KIND_POISSON>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1);
+      case KIND_PLANE:   return launch_K<KIND_PLANE>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1);
+      default:           return launch_K<KIND_ELASTIC>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1);
     }
+  };
+  p->used_fast = false;
+  HIPCHK(hipMemsetAsync(p->bad, 0, 4 * sizeof(unsigned long long), p->stream));
+  rc = launch_rect_check(p);
+  if (rc) return rc;
+  p->iface_rect = p->rect_checked;
+  rc = layer_K();
+  if (rc) return rc;
+  if (p->used_fast) {
+    // The caller is about to hand the buffer to the network, so it has to be final when the stream gets there, and
+    // the host does not wait for the fast kernel's verdict: the general kernels are queued behind it on the same
+    // rows and return at once unless the premise flag is set (one layer: their full run is 1/layers of a general
+    // assembly).  Flags are read back by the femasm_assemble_system call that follows, which also drops the
+    // plan's level.
+    const int level = p->fast_level;
+    p->fast_level = 0;
+    p->cond_general = true;
+    rc = layer_K();
+    p->cond_general = false;
+    p->fast_level = level;
+    p->used_fast = false;
     if (rc) return rc;
-    // one layer only: checking the fast kernel's premise here costs one short wait, and the caller is about to
-    // hand the buffer to the network, so it has to be final
-    HIPCHK(hipMemcpyAsync(flags, p->bad, sizeof flags, hipMemcpyDeviceToHost, p->stream));
-    HIPCHK(hipStreamSynchronize(p->stream));
-    if (!(p->used_fast && flags[1])) break;
-    p->fast_level = (p->kind == KIND_POISSON && p->fast_level == 2) ? 1 : 0;
   }
-  if (flags[2]) return fail(FEMASM_ERR_HIP, "internal: %llu wave hand-shakes of the row-sweep kernel timed out", flags[2]);
-  if (flags[0]) return fail(FEMASM_ERR_GEOMETRY, "%llu Gauss points with non-positive or NaN det(J)", flags[0]);
   // element vectors of the one element layer that touches node layer ks-1 from above (it is the first layer
   // of the plan's element-vector array, where the full call will write the same numbers again)
   Slab sl = s;

@@ -133,6 +133,8 @@ struct KArgs {
   int32_t iface;          // 1: interface pass (elastic BC rows become zero rows)
   int32_t zc;             // row-sweep kernels: node layers (rows in 2-D) per workgroup
   int32_t rect;           // row-sweep kernels: the mesh was verified rectilinear (k_check_rectilinear): geometry from 1-D lines
+  int32_t cond;           // general kernels: run only if bad[1] != 0, i.e. the fast kernel launched before on the same rows
+                          // found its premise broken (femasm_assemble_interface: no host round trip)
 };
 
 // isotropic coefficient triple scaled by w*detJ, in the reference's operation order
@@ -269,6 +271,7 @@ __device__ inline bool is_bc_node(const Slab &s, int bc, int64_t i, int64_t j, i
 template <int KIND>
 __global__ __launch_bounds__(256, 2) void k_assemble_rows(const Slab s, const KArgs a) {
   using T = Traits<KIND>;
+  if (a.cond && a.bad[1] == 0) return;
   constexpr int NSD = T::NSD, DOF = T::DOF, NEN = T::NEN, NGP = T::NGP, NCOEF = T::NCOEF;
   constexpr int BX = T::BX, BY = T::BY, BZ = T::BZ;
   constexpr int EX = BX + 1, EY = BY + 1, EZ = (NSD == 3) ? BZ + 1 : 1;

@@ -156,6 +156,7 @@ __device__ inline void sweep_store_third(const Slab &s, const KArgs &a, const do
 template <int KIND>
 __global__ __launch_bounds__(256, 2) void k_assemble_sweep(const Slab s, const KArgs a) {
   using T = Traits<KIND>;
+  if (a.cond && a.bad[1] == 0) return;
   constexpr int DOF = T::DOF, DD = DOF * DOF, NACC = 9 * DD;
   constexpr int NPAIR = 14;
   constexpr int CH = 9 * DOF;              // doubles of one (node,row) chunk of a third
@@ -368,6 +369,7 @@ __device__ inline void sweep_contract_p3(const double2 *__restrict__ rec, int my
 }
 
 __global__ __launch_bounds__(256, 2) void k_assemble_sweep_p3(const Slab s, const KArgs a) {
+  if (a.cond && a.bad[1] == 0) return;
   constexpr int KIND = KIND_POISSON, NACC = 9, NPAIR = 24, CH = 9;
   static_assert(3 * 64 * CH * 8 <= NPAIR * SW_NS * 16, "staging aliases the record buffer");
   __shared__ double2 sh_rec[NPAIR * SW_NS];  // 46 080 B: C_p of the 8 Gauss points, pair-SoA rec[3p + q][slot]
@@ -1364,6 +1366,7 @@ __global__ __launch_bounds__(64) void k_assemble_e2_rect(const Slab s, const KAr
 // interface pass: zero rows (the receiver ignores them).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_bc_rows(const Slab s, const KArgs a) {
+  if (a.cond && a.bad[1] == 0) return;
   const int64_t M = s.dim[0], N = s.dim[1];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // x-rows of nodes (j, k) are walked with a stride (most rows have two Dirichlet nodes only); S3 128^3: 45 us =

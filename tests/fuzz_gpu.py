@@ -144,6 +144,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-cases", type=int, default=100000)
+    ap.add_argument("--split-only", action="store_true", help="only multi-slab cases with the split interface call")
     args = ap.parse_args()
     import torch
     from oracle import oracle as O
@@ -172,6 +173,10 @@ def main():
         SL = dims[-1]
         nslab = int(rng.integers(1, min(4, SL // 2) + 1)) if SL >= 4 else 1
         split = bool(rng.integers(0, 2))
+        if args.split_only:
+            if SL < 4:
+                continue
+            nslab, split = max(nslab, 2), True
         tag = f"seed={args.seed} case={n} {kind} dims={dims} mesh={mesh} material={material} nslab={nslab} split={split}"
         case = make_case(O, F, rng, kind, dims, mesh, material)
         K, b, levels = run_slabs(torch, F, slab, dev, case, nslab, split)
