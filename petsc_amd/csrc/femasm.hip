@@ -335,6 +335,19 @@ int launch_rhs(femasm_plan *p, const femasm_material *mat, int bc, double *out, 
     hipLaunchKernelGGL(k_poisson_rhs_rect, g3, dim3(256), 0, p->stream, sl, a, p->lines);
     HIPCHK(hipGetLastError());
   }
+  if constexpr (KIND == KIND_PLANE) {
+    // E2: element integration and node sum in one pass (k_rhs_e2_fused), no element-vector array
+    const bool live = a.gp != nullptr && a.mat_layout == FEMASM_MAT_AOS && sl.ele > sl.els && p->s.dim[0] > 1;
+    const bool al = (((uintptr_t)a.gp | (uintptr_t)a.coords) & 15) == 0 && (a.mat_stride & 1) == 0;
+    const int64_t nwx = (p->s.dim[0] + 62) / 63, ngy = (s1 - s0 + E2R_YC - 1) / E2R_YC;
+    if (ngy > 65535) return fail(FEMASM_ERR_ARG, "mesh too large for one launch");
+    const dim3 fgrid((unsigned)((nwx + 3) / 4), (unsigned)ngy, 1);
+    if (!live) hipLaunchKernelGGL((k_rhs_e2_fused<false, false>), fgrid, dim3(256), 0, p->stream, sl, a);
+    else if (al) hipLaunchKernelGGL((k_rhs_e2_fused<true, true>), fgrid, dim3(256), 0, p->stream, sl, a);
+    else hipLaunchKernelGGL((k_rhs_e2_fused<false, true>), fgrid, dim3(256), 0, p->stream, sl, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   if (do_elem && nel > 0) {
     if (runs) {
       // persistent one-wave workgroups: one resident set (occupancy queried once per plan)

@@ -1130,6 +1130,43 @@ __global__ __launch_bounds__(256) void k_op_elem(const Slab s, const RArgs a, do
   for (int q = 0; q < NEN * DOF; q++) a.elemF[ef_idx<NEN * DOF>(e, q)] = F[q];
 }
 
+// Dirichlet rows of b (and of the operator apply): the value the drivers set after the element loop
+template <int KIND>
+__device__ inline void rhs_dirichlet(const Slab &s, const RArgs &a, int64_t i, int64_t j, int64_t k, double *b) {
+  using T = Traits<KIND>;
+  constexpr int NSD = T::NSD, DOF = T::DOF;
+  const int64_t M = s.dim[0], N = s.dim[1];
+  if (is_bc_node(s, a.bc, i, j, k)) {
+    if (a.iface) {
+      // partial sums owed to the rank below: Dirichlet rows are ignored by the receiver
+#pragma unroll
+      for (int c = 0; c < DOF; c++) b[c] = 0.0;
+    } else if (a.x) {
+      // operator apply: a Dirichlet row is diag * e_row (diag 1; Poisson: valence of the assembled elements)
+      double diag = 1.0;
+      if (a.bc == BC_POISSON) {
+        const int vx = (i > 0) + (i < M - 1), vy = (j > 0) + (j < N - 1);
+        const int vz = (k - 1 >= s.els && k - 1 < s.ele) + (k >= s.els && k < s.ele);
+        diag = (double)(vx * vy * vz);
+      }
+      const int64_t node = (NSD == 3) ? i + M * (j + N * (k - s.cks)) : i + M * (j - s.cks);
+#pragma unroll
+      for (int c = 0; c < DOF; c++) b[c] = diag * a.x[node * DOF + c];
+    } else if (a.bc == BC_POISSON) {
+      b[0] = 0.0;                                   // P3:624-630
+    } else if (a.bc == BC_E2) {
+      b[0] = (i == M - 1) ? -1.0 : 1.0;             // E2:882-885
+      if constexpr (DOF > 1) b[1] = 0.0;
+    } else if (a.bc == BC_S3) {
+      constexpr double PI = 3.14159265358979323846264338327950288;
+      const int64_t node = i + M * (j + N * (k - s.cks));
+      const double x = a.coords[3 * node], y = a.coords[3 * node + 1], z = a.coords[3 * node + 2];
+      b[0] = 0.0;                                   // S3:964-968 via S3:1501-1505
+      if constexpr (DOF > 2) { b[1] = 0.0; b[2] = sin(PI * x) * sin(PI * y) * sin(PI * z); }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // RHS, pass 2: one thread per node; contributions added in the reference's element
 // order (k -> j -> i) (S3: Fe + Ge of an element enter as one term); then the Dirichlet value.
@@ -1199,35 +1236,7 @@ __device__ inline void rhs_gather_node(const Slab &s, const RArgs &a, int64_t i,
       }
   }
 
-  if (is_bc_node(s, a.bc, i, j, k)) {
-    if (a.iface) {
-      // partial sums owed to the rank below: Dirichlet rows are ignored by the receiver
-#pragma unroll
-      for (int c = 0; c < DOF; c++) b[c] = 0.0;
-    } else if (a.x) {
-      // operator apply: a Dirichlet row is diag * e_row (diag 1; Poisson: valence of the assembled elements)
-      double diag = 1.0;
-      if (a.bc == BC_POISSON) {
-        const int vx = (i > 0) + (i < M - 1), vy = (j > 0) + (j < N - 1);
-        const int vz = (k - 1 >= s.els && k - 1 < s.ele) + (k >= s.els && k < s.ele);
-        diag = (double)(vx * vy * vz);
-      }
-      const int64_t node = (NSD == 3) ? i + M * (j + N * (k - s.cks)) : i + M * (j - s.cks);
-#pragma unroll
-      for (int c = 0; c < DOF; c++) b[c] = diag * a.x[node * DOF + c];
-    } else if (a.bc == BC_POISSON) {
-      b[0] = 0.0;                                   // P3:624-630
-    } else if (a.bc == BC_E2) {
-      b[0] = (i == M - 1) ? -1.0 : 1.0;             // E2:882-885
-      if constexpr (DOF > 1) b[1] = 0.0;
-    } else if (a.bc == BC_S3) {
-      constexpr double PI = 3.14159265358979323846264338327950288;
-      const int64_t node = i + M * (j + N * (k - s.cks));
-      const double x = a.coords[3 * node], y = a.coords[3 * node + 1], z = a.coords[3 * node + 2];
-      b[0] = 0.0;                                   // S3:964-968 via S3:1501-1505
-      if constexpr (DOF > 2) { b[1] = 0.0; b[2] = sin(PI * x) * sin(PI * y) * sin(PI * z); }
-    }
-  }
+  rhs_dirichlet<KIND>(s, a, i, j, k, b);
 #pragma unroll
   for (int c = 0; c < DOF; c++) a.out[q * DOF + c] = b[c];
 }
@@ -1242,6 +1251,103 @@ __global__ __launch_bounds__(256) void k_rhs_gather(const Slab s, const RArgs a)
   const int64_t ny = (Traits<KIND>::NSD == 3) ? s.dim[1] : a.s1 - a.s0, nz = (Traits<KIND>::NSD == 3) ? a.s1 - a.s0 : 1;
   for (int64_t bz = blockIdx.z; bz < nz; bz += gridDim.z)
     for (int64_t by = blockIdx.y; by < ny; by += gridDim.y) rhs_gather_node<KIND, RUNS>(s, a, i, by, bz);
+}
+
+// ---------------------------------------------------------------------------
+// E2 right-hand side in one pass (no element-vector array).  A wave owns 64 x-consecutive elements and the 63 nodes
+// between them (lane l: element column ex = n0 - 1 + l and, for l >= 1, node column i = ex) and walks E2R_YC node
+// rows upwards: per element row every lane integrates its element's Fe (E2:325-350: 4 corner nodes, fx/fy at the 4
+// Gauss points = 64 of the record's 192 bytes, read one row ahead), a node's four terms are added in the
+// reference's element order (j-1 before j, i-1 before i) -- the two of the left-hand element come from lane l-1, the
+// two of the row below from the previous step.  Every input is read once (+1/63 in x, +1/E2R_YC in y), b written once.
+// ---------------------------------------------------------------------------
+constexpr int E2R_YC = 16;
+struct E2RIn { double xc[8]; double f[8]; };
+template <bool ALIGNED>
+__device__ inline void e2r_load(const Slab &s, const RArgs &a, int64_t exc, int64_t ey, E2RIn &o) {
+  const int64_t M = s.dim[0], mx = M - 1;
+  // element row clamped to the assembled ones (the caller discards the result of a clamped row)
+  const int64_t eyc = ey < s.els ? s.els : (ey >= s.ele ? s.ele - 1 : ey);
+  const double *c0 = a.coords + 2 * (exc + M * (eyc - s.cks)), *c1 = c0 + 2 * M;
+  const double *q = a.gp + (exc + mx * (eyc - s.mat_e_ks)) * (int64_t)a.mat_stride + 16;
+  if constexpr (ALIGNED) {
+    const double2 n0 = *(const double2 *)c0, n3 = *(const double2 *)(c0 + 2);
+    const double2 n1 = *(const double2 *)c1, n2 = *(const double2 *)(c1 + 2);
+    o.xc[0] = n0.x; o.xc[1] = n0.y; o.xc[2] = n1.x; o.xc[3] = n1.y;
+    o.xc[4] = n2.x; o.xc[5] = n2.y; o.xc[6] = n3.x; o.xc[7] = n3.y;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const double2 v = *(const double2 *)(q + 2 * t);
+      o.f[2 * t] = v.x; o.f[2 * t + 1] = v.y;
+    }
+  } else {
+    o.xc[0] = c0[0]; o.xc[1] = c0[1]; o.xc[2] = c1[0]; o.xc[3] = c1[1];
+    o.xc[4] = c1[2]; o.xc[5] = c1[3]; o.xc[6] = c0[2]; o.xc[7] = c0[3];
+#pragma unroll
+    for (int t = 0; t < 8; t++) o.f[t] = q[t];
+  }
+}
+
+template <bool ALIGNED, bool LIVE /* AoS material and at least one element row: else every Fe is zero */>
+__global__ __launch_bounds__(256) void k_rhs_e2_fused(const Slab s, const RArgs a) {
+  const int64_t M = s.dim[0], mx = M - 1;
+  const int lane = threadIdx.x & 63;
+  const int64_t n0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 63;
+  if (n0 >= M) return;
+  const int64_t ex = n0 - 1 + lane;
+  const bool ex_ok = ex >= 0 && ex < mx;
+  const int64_t exc = ex < 0 ? 0 : (ex >= mx ? mx - 1 : ex);
+  const bool node_ok = lane >= 1 && ex < M;
+  const int64_t ny = a.s1 - a.s0;
+  const int64_t by0 = (int64_t)blockIdx.y * E2R_YC, by1 = by0 + E2R_YC < ny ? by0 + E2R_YC : ny;
+  constexpr bool live = LIVE;
+  E2RIn nxt;
+#pragma unroll
+  for (int t = 0; t < 8; t++) { nxt.xc[t] = 0.0; nxt.f[t] = 0.0; }
+  if (live) e2r_load<ALIGNED>(s, a, exc, a.s0 + by0 - 1, nxt);
+  double lo1[2] = {0.0, 0.0}, lo2[2] = {0.0, 0.0};  // Fe of the element row below: local nodes 1 (0,1) and 2 (1,1)
+  for (int64_t by = by0 - 1; by < by1; by++) {
+    const int64_t ey = a.s0 + by;  // element row; also the node row written in this step (if by >= by0)
+    const E2RIn cur = nxt;
+    if (live) e2r_load<ALIGNED>(s, a, exc, ey + 1, nxt);  // unconditional (clamped): stays in flight over the step
+    double F[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) F[t] = 0.0;
+    if (live) {
+      for (int p = 0; p < 4; p++) {  // E2:339-349
+        const Jac2 jj = jac2(c_tab2.G[p], cur.xc);
+        const double fac = 1.0 * jj.det;
+        const double fx = cur.f[p], fy = cur.f[4 + p];
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+          F[2 * n] += fac * c_tab2.N[p][n] * fx;
+          F[2 * n + 1] += fac * c_tab2.N[p][n] * fy;
+        }
+      }
+    }
+    const bool el_ok = ex_ok && ey >= s.els && ey < s.ele;
+#pragma unroll
+    for (int t = 0; t < 8; t++) F[t] = el_ok ? F[t] : 0.0;
+    if (by >= by0) {
+      double b[2];
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        const double l2 = __shfl_up(lo2[c], 1), l3 = __shfl_up(F[6 + c], 1);
+        b[c] = 0.0 + l2;          // element (i-1, j-1), its node (1,1)
+        b[c] = b[c] + lo1[c];     // element (i,   j-1), its node (0,1)
+        b[c] = b[c] + l3;         // element (i-1, j  ), its node (1,0)
+        b[c] = b[c] + F[c];       // element (i,   j  ), its node (0,0)
+      }
+      if (node_ok) {
+        rhs_dirichlet<KIND_PLANE>(s, a, ex, ey, 0, b);
+        double *o = a.out + 2 * (ex + M * by);
+        o[0] = b[0];
+        o[1] = b[1];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++) { lo1[c] = F[2 + c]; lo2[c] = F[4 + c]; }
+  }
 }
 
 // ---------------------------------------------------------------------------

@@ -144,6 +144,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-cases", type=int, default=100000)
+    ap.add_argument("--kinds", default="p3,e2,s3")
     ap.add_argument("--split-only", action="store_true", help="only multi-slab cases with the split interface call")
     args = ap.parse_args()
     import torch
@@ -158,7 +159,7 @@ def main():
     n = 0
     worst = 0.0
     while time.time() < t_end and n < args.max_cases:
-        kind = rng.choice(["p3", "e2", "s3"])
+        kind = rng.choice(args.kinds.split(","))
         while True:
             if kind == "e2":
                 dims = (int(rng.choice(XS + [257, 513])), int(rng.choice(YS + [97, 130])))
