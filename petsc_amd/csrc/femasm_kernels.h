@@ -1261,7 +1261,10 @@ __global__ __launch_bounds__(256) void k_rhs_gather(const Slab s, const RArgs a)
 // reference's element order (j-1 before j, i-1 before i) -- the two of the left-hand element come from lane l-1, the
 // two of the row below from the previous step.  Every input is read once (+1/63 in x, +1/E2R_YC in y), b written once.
 // ---------------------------------------------------------------------------
-constexpr int E2R_YC = 16;
+#ifndef FEMASM_E2R_YC
+#define FEMASM_E2R_YC 8
+#endif
+constexpr int E2R_YC = FEMASM_E2R_YC;
 struct E2RIn { double xc[8]; double f[8]; };
 template <bool ALIGNED>
 __device__ inline void e2r_load(const Slab &s, const RArgs &a, int64_t exc, int64_t ey, E2RIn &o) {
@@ -1305,11 +1308,20 @@ __global__ __launch_bounds__(256) void k_rhs_e2_fused(const Slab s, const RArgs 
 #pragma unroll
   for (int t = 0; t < 8; t++) { nxt.xc[t] = 0.0; nxt.f[t] = 0.0; }
   if (live) e2r_load<ALIGNED>(s, a, exc, a.s0 + by0 - 1, nxt);
+#ifdef FEMASM_E2R_PF2
+  E2RIn nx2 = nxt;
+  if (live) e2r_load<ALIGNED>(s, a, exc, a.s0 + by0, nx2);
+#endif
   double lo1[2] = {0.0, 0.0}, lo2[2] = {0.0, 0.0};  // Fe of the element row below: local nodes 1 (0,1) and 2 (1,1)
   for (int64_t by = by0 - 1; by < by1; by++) {
     const int64_t ey = a.s0 + by;  // element row; also the node row written in this step (if by >= by0)
     const E2RIn cur = nxt;
+#ifdef FEMASM_E2R_PF2
+    nxt = nx2;
+    if (live) e2r_load<ALIGNED>(s, a, exc, ey + 2, nx2);
+#else
     if (live) e2r_load<ALIGNED>(s, a, exc, ey + 1, nxt);  // unconditional (clamped): stays in flight over the step
+#endif
     double F[8];
 #pragma unroll
     for (int t = 0; t < 8; t++) F[t] = 0.0;
