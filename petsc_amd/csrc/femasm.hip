@@ -81,6 +81,7 @@ struct femasm_plan {
   int64_t send_count = 0, recv_count = 0, send_nnz = 0, recv_nnz = 0;
   bool own_send = true, own_recv = true;
 
+  unsigned long long *flags_host = nullptr;  // pinned: the flags' read-back is a real asynchronous copy, not a staged one
   unsigned long long *bad = nullptr;   // [0] Gauss points with det(J) <= 0, [1] elements that failed the affine test
   int fast_level = 2;                  // 3-D kinds: try the row-sweep kernel (include/femasm.h), 0 = general
   bool used_fast = false;
@@ -476,6 +477,7 @@ int femasm_plan_create(const femasm_mesh *mesh, const femasm_quad *quad, int dev
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) p->ncu = prop.multiProcessorCount;
   }
+  PCHK(hipHostMalloc(&p->flags_host, 4 * sizeof(unsigned long long), hipHostMallocDefault));
   PCHK(hipMalloc(&p->bad, 32 * sizeof(unsigned long long)));  // [0] bad detJ, [1] fast-path premise failures, [2] hand-shake timeouts, rest: profiling builds
   PCHK(hipMemsetAsync(p->bad, 0, 32 * sizeof(unsigned long long), p->stream));
   // element vectors: blocks of 16 elements x nen*dof lines (ef_idx in femasm_kernels.h)
@@ -527,6 +529,7 @@ int femasm_plan_destroy(femasm_plan *p) {
                   p->own_recv ? p->recv : nullptr, p->bad, p->stage_vals, p->stage_b, p->stage_gp, p->lines};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
+  if (p->flags_host) (void)hipHostFree(p->flags_host);
   for (auto &e : p->ev)
     if (e) (void)hipEventDestroy(e);
   if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
@@ -709,8 +712,9 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
   t0 = std::chrono::steady_clock::now();
   if (vals_host) HIPCHK(hipMemcpyAsync(csr_values, d_vals, p->nnz * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   if (b_host) HIPCHK(hipMemcpyAsync(b, d_b, p->nrows * sizeof(double), hipMemcpyDeviceToHost, p->stream));
-  unsigned long long flags[3] = {0, 0, 0};
-  HIPCHK(hipMemcpyAsync(flags, p->bad, sizeof flags, hipMemcpyDeviceToHost, p->stream));
+  unsigned long long *flags = p->flags_host;
+  flags[0] = flags[1] = flags[2] = 0;
+  HIPCHK(hipMemcpyAsync(flags, p->bad, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, p->stream));
   HIPCHK(hipStreamSynchronize(p->stream));
   if (vals_host || b_host)
     ms_staging += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -729,7 +733,7 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
     t0 = std::chrono::steady_clock::now();
     rc = run_K();
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(flags, p->bad, sizeof flags, hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipMemcpyAsync(flags, p->bad, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     k_ms_redo = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (vals_host && !(p->used_fast && flags[1])) {
