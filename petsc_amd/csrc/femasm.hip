@@ -651,6 +651,7 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
   ms_staging += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
   int rc = 0;
+  if (stats) HIPCHK(hipEventRecord(p->ev[0], p->stream));  // ms_kernel_K includes the rectilinearity pre-pass
   if (p->iface_done) {
     // femasm_assemble_interface ran just before on the same inputs without reading its flags back: they carry
     // over (a broken premise or a timed-out hand-shake there is found here), and so does the verdict of its
@@ -683,7 +684,6 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
   p->used_fast = false;
   p->time_main = stats != nullptr;
   p->bytes_main = 0.0;
-  if (stats) HIPCHK(hipEventRecord(p->ev[0], p->stream));
   if (d_vals) {
     rc = run_K();
     if (rc) return rc;
