@@ -203,12 +203,6 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
     return rc2;
   } else {
     const bool shell_is_bc = (bc == FEMASM_BC_POISSON_INLOOP || bc == FEMASM_BC_S3_ALLFACES_EXACT);
-    if (shell_is_bc) {  // Dirichlet rows of the boundary shell
-      const KArgs a = make_kargs<KIND>(p, mat, bc, out, Box{0, M, 0, N, s0, s1}, s0, iface);
-      const int64_t nrow = N * (s1 - s0);
-      hipLaunchKernelGGL(k_bc_rows, dim3((unsigned)(nrow < 8192 ? nrow : 8192)), dim3(256), 0, p->stream, p->s, a);
-      HIPCHK(hipGetLastError());
-    }
     // interior nodes (full 27-neighbour stencil): z-sweep kernel
     const int64_t z0 = s0 > 1 ? s0 : 1, z1 = s1 < P - 1 ? s1 : P - 1;
     if (M > 2 && N > 2 && z1 > z0) {
@@ -255,6 +249,14 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
       }
       HIPCHK(hipGetLastError());
       if (timed) HIPCHK(hipEventRecord(p->ev[5], p->stream));
+    }
+    if (shell_is_bc) {
+      // Dirichlet rows of the boundary shell, AFTER the interior kernel: this small store kernel then runs while the
+      // interior kernel's dirty lines drain, and the read-bound RHS kernels that follow start on a quiet memory system
+      const KArgs a = make_kargs<KIND>(p, mat, bc, out, Box{0, M, 0, N, s0, s1}, s0, iface);
+      const int64_t nrow = N * (s1 - s0);
+      hipLaunchKernelGGL(k_bc_rows, dim3((unsigned)(nrow < 8192 ? nrow : 8192)), dim3(256), 0, p->stream, p->s, a);
+      HIPCHK(hipGetLastError());
     }
     if (!shell_is_bc) {  // boundary rows that are real equations: general brick kernel on the six faces
       int rc = 0;
@@ -371,8 +373,8 @@ int launch_rhs(femasm_plan *p, const femasm_material *mat, int bc, double *out, 
   }
   // (the gather walks its logical grid with strides in y and z: capped launch)
   auto capped = [](int64_t n, int64_t cap) { return (unsigned)(n < cap ? n : cap); };
-  const dim3 ggrid = (T::NSD == 3) ? dim3(nblk(p->s.dim[0]), capped(p->s.dim[1], 128), capped(s1 - s0, 32))
-                                   : dim3(nblk(p->s.dim[0]), capped(s1 - s0, 1024), 1);
+  const dim3 ggrid = (T::NSD == 3) ? dim3(capped((p->s.dim[0] * p->s.dim[1] + 255) / 256, 1024), 1, capped(s1 - s0, 64))
+                                   : dim3(capped((p->s.dim[0] * (s1 - s0) + 255) / 256, 16384), 1, 1);
   if constexpr (KIND == KIND_ELASTIC) {
     if (runs) hipLaunchKernelGGL((k_rhs_gather<KIND_ELASTIC, true>), ggrid, dim3(256), 0, p->stream, sl, a);
     else hipLaunchKernelGGL(k_rhs_gather<KIND>, ggrid, dim3(256), 0, p->stream, sl, a);
@@ -915,8 +917,9 @@ int femasm_apply_operator(femasm_plan *p, const femasm_material *mat, const fema
     g.s0 = s0;
     g.s1 = s1;
     g.iface = iface;
-    const dim3 grid = (s.nsd == 3) ? dim3(nblk(s.dim[0]), (unsigned)s.dim[1], (unsigned)(s1 - s0))
-                                   : dim3(nblk(s.dim[0]), (unsigned)(s1 - s0), 1);
+    auto capped = [](int64_t n, int64_t cap) { return (unsigned)(n < cap ? n : cap); };
+    const dim3 grid = (s.nsd == 3) ? dim3(capped((s.dim[0] * s.dim[1] + 255) / 256, 1024), 1, capped(s1 - s0, 64))
+                                   : dim3(capped((s.dim[0] * (s1 - s0) + 255) / 256, 16384), 1, 1);
     switch (p->kind) {
       case KIND_POISSON: hipLaunchKernelGGL(k_rhs_gather<KIND_POISSON>, grid, dim3(256), 0, p->stream, s, g); break;
       case KIND_PLANE:   hipLaunchKernelGGL(k_rhs_gather<KIND_PLANE>, grid, dim3(256), 0, p->stream, s, g); break;

@@ -1240,17 +1240,21 @@ __device__ inline void rhs_gather_node(const Slab &s, const RArgs &a, int64_t i,
 #pragma unroll
   for (int c = 0; c < DOF; c++) a.out[q * DOF + c] = b[c];
 }
-// logical grid (ceil(M/256), N or layers, layers or 1), walked with strides in y and z (the launch caps them)
+// one thread per node of a node layer taken as a flat (i, j) plane (every lane busy whatever M is); grid (x, 1, z)
+// walked with strides (the launch caps it)
 template <int KIND, bool RUNS = false>
 __global__ __launch_bounds__(256) void k_rhs_gather(const Slab s, const RArgs a) {
   if constexpr (KIND == KIND_POISSON) {
     if (a.rect != 0 && a.bad[3] == 0ULL) return;  // rectilinear mesh: k_poisson_rhs_rect has written b
   }
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= s.dim[0]) return;
+  const int64_t M = s.dim[0];
   const int64_t ny = (Traits<KIND>::NSD == 3) ? s.dim[1] : a.s1 - a.s0, nz = (Traits<KIND>::NSD == 3) ? a.s1 - a.s0 : 1;
+  const int64_t plane = M * ny;
   for (int64_t bz = blockIdx.z; bz < nz; bz += gridDim.z)
-    for (int64_t by = blockIdx.y; by < ny; by += gridDim.y) rhs_gather_node<KIND, RUNS>(s, a, i, by, bz);
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < plane; n += (int64_t)gridDim.x * 256) {
+      const int64_t by = n / M;
+      rhs_gather_node<KIND, RUNS>(s, a, n - by * M, by, bz);
+    }
 }
 
 // ---------------------------------------------------------------------------
