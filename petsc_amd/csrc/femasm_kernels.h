@@ -1174,7 +1174,7 @@ __device__ inline void rhs_dirichlet(const Slab &s, const RArgs &a, int64_t i, i
 template <int KIND, bool RUNS>
 __device__ inline void rhs_gather_node(const Slab &s, const RArgs &a, int64_t i, int64_t by, int64_t bz) {
   using T = Traits<KIND>;
-  constexpr int NSD = T::NSD, DOF = T::DOF, NFE = T::NFE;
+  constexpr int NSD = T::NSD, DOF = T::DOF;
   const int64_t M = s.dim[0], N = s.dim[1];
   const int64_t mx = M - 1, my = N - 1;
   int64_t j, k, q;

@@ -160,8 +160,6 @@ __global__ __launch_bounds__(256, 2) void k_assemble_sweep(const Slab s, const K
   constexpr int DOF = T::DOF, DD = DOF * DOF, NACC = 9 * DD;
   constexpr int NPAIR = 14;
   constexpr int CH = 9 * DOF;              // doubles of one (node,row) chunk of a third
-  constexpr int NODESTRIDE = 27 * DD;      // doubles between the rows of x-neighbouring nodes
-  constexpr int NIT = (SW_TX * CH + 63) / 64;
   static_assert(3 * 64 * CH * 8 <= 2 * NPAIR * SW_NS * 16, "staging aliases the record buffers");
 
   __shared__ double2 sh_rec[2 * NPAIR * SW_NS];   // 53 760 B
