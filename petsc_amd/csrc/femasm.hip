@@ -205,6 +205,7 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
     const bool shell_is_bc = (bc == FEMASM_BC_POISSON_INLOOP || bc == FEMASM_BC_S3_ALLFACES_EXACT);
     // interior nodes (full 27-neighbour stencil): z-sweep kernel
     const int64_t z0 = s0 > 1 ? s0 : 1, z1 = s1 < P - 1 ? s1 : P - 1;
+    bool ends_done = false;  // the interior kernel also wrote the Dirichlet rows of the x-end nodes of its lines
     if (M > 2 && N > 2 && z1 > z0) {
       const Box b{1, M - 1, 1, N - 1, z0, z1};
       const KArgs a = make_kargs<KIND>(p, mat, bc, out, b, s0, iface);
@@ -232,6 +233,8 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
         az.zc = (int32_t)zc;
         az.rect = rect ? 1 : 0;
         if (KIND == KIND_POISSON && rect) {  // dof 1 on a rectilinear mesh: autonomous waves, one tile row each
+          ends_done = shell_is_bc;
+          az.ends = ends_done ? 1 : 0;
           dim3 grid((unsigned)((b.x1 - b.x0 + P3W_TX - 1) / P3W_TX), (unsigned)(b.y1 - b.y0),
                     (unsigned)((z1 - z0 + zc - 1) / zc));
           hipLaunchKernelGGL(k_assemble_p3_rect, grid, dim3(64), 0, p->stream, p->s, az);
@@ -253,8 +256,10 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
     if (shell_is_bc) {
       // Dirichlet rows of the boundary shell, AFTER the interior kernel: this small store kernel then runs while the
       // interior kernel's dirty lines drain, and the read-bound RHS kernels that follow start on a quiet memory system
-      const KArgs a = make_kargs<KIND>(p, mat, bc, out, Box{0, M, 0, N, s0, s1}, s0, iface);
+      KArgs a = make_kargs<KIND>(p, mat, bc, out, Box{0, M, 0, N, s0, s1}, s0, iface);
+      a.ends = ends_done ? 1 : 0;
       const int64_t nrow = N * (s1 - s0);
+      if (nrow >= ((int64_t)1 << 31)) return fail(FEMASM_ERR_ARG, "mesh too large for one launch");
       hipLaunchKernelGGL(k_bc_rows, dim3((unsigned)(nrow < 8192 ? nrow : 8192)), dim3(256), 0, p->stream, p->s, a);
       HIPCHK(hipGetLastError());
     }

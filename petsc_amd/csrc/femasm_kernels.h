@@ -133,6 +133,7 @@ struct KArgs {
   int32_t iface;          // 1: interface pass (elastic BC rows become zero rows)
   int32_t zc;             // row-sweep kernels: node layers (rows in 2-D) per workgroup
   int32_t rect;           // row-sweep kernels: the mesh was verified rectilinear (k_check_rectilinear): geometry from 1-D lines
+  int32_t ends;           // the interior kernel writes the Dirichlet rows of the x-end nodes of its lines; k_bc_rows skips them
   int32_t cond;           // general kernels: run only if bad[1] != 0, i.e. the fast kernel launched before on the same rows
                           // found its premise broken (femasm_assemble_interface: no host round trip)
 };

@@ -1066,8 +1066,8 @@ __global__ __launch_bounds__(64 * (3 + RowSweep<KIND>::NRW), 2) void k_assemble_
 // ---------------------------------------------------------------------------
 constexpr int P3W_TX = 64;
 __global__ __launch_bounds__(64) void k_assemble_p3_rect(const Slab s, const KArgs a) {
-  constexpr int ROW = 27, RUN = P3W_TX * ROW;
-  __shared__ double sh_stage[RUN];
+  constexpr int ROW = 27, RUN = P3W_TX * ROW, END = 18;  // END: values of the row of an x-end node (2 x 3 x 3 neighbours)
+  __shared__ double sh_stage[END + RUN + END];
   const int lane = threadIdx.x;
   const int64_t M = s.dim[0], N = s.dim[1];
   const int64_t i0 = a.x0 + (int64_t)blockIdx.x * P3W_TX, j = a.y0 + blockIdx.y;
@@ -1080,6 +1080,10 @@ __global__ __launch_bounds__(64) void k_assemble_p3_rect(const Slab s, const KAr
   const double xm = a.coords[3 * (i - 1)], xc = a.coords[3 * i], xp = a.coords[3 * (i + 1)];
   const double ym = a.coords[3 * (M * (j - 1)) + 1], yc = a.coords[3 * (M * j) + 1], yp = a.coords[3 * (M * (j + 1)) + 1];
   const double Jx[2] = {0.5 * (xc - xm), 0.5 * (xp - xc)}, Jy[2] = {0.5 * (yc - ym), 0.5 * (yp - yc)};
+  // a.ends (Dirichlet shell, P3:286-290): the rows of the x-end nodes 0 and M-1 of this (j, k) line sit right before
+  // and after the interior rows in the value array; the first and last wave of the line write them with their run
+  // (diag * e_row, diag = valence of the node in the assembled elements), so no line of K is written in two goes
+  const int pre = (a.ends && i0 == 1) ? END : 0, post = (a.ends && i0 + nvx == M - 1) ? END : 0;
   auto zline = [&](int64_t k) { return a.coords[3 * (M * N * (k - s.cks)) + 2]; };
   // C of the four elements (oy, ox) of element layer L; zero outside the layers this rank assembles
   auto layer = [&](int64_t L, double (*C)[3]) {
@@ -1138,17 +1142,24 @@ __global__ __launch_bounds__(64) void k_assemble_p3_rect(const Slab s, const KAr
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();  // the previous step's reads of the stage are done
     {
-      double *dst = sh_stage + lane * ROW;
+      double *dst = sh_stage + pre + lane * ROW;
 #pragma unroll
       for (int q = 0; q < ROW; q++) dst[q] = acc[q];
     }
+    if (pre + post) {
+      const int vz = (kn - 1 >= s.els && kn - 1 < s.ele) + (kn >= s.els && kn < s.ele);
+      const double diag = (double)(1 * 2 * vz);  // x-end node of an interior (j, k) line
+      // self position among the (dk, dj, di) neighbours: di in {0,1} at node 0 -> 8, di in {-1,0} at node M-1 -> 9
+      if (pre && lane < END) sh_stage[lane] = (lane == 8) ? diag : 0.0;
+      if (post && lane < END) sh_stage[pre + nvx * ROW + lane] = (lane == 9) ? diag : 0.0;
+    }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    const int n = nvx * ROW;
-    double *runp = a.out + (row_start(s, i0, j, kn, 0) - a.base_off);
+    const int n = pre + nvx * ROW + post;
+    double *runp = a.out + (row_start(s, i0, j, kn, 0) - a.base_off) - pre;
     const int head = (int)((reinterpret_cast<uintptr_t>(runp) & 127) >> 3);  // doubles above a line boundary
     const int nchunk = (head + n + 1) >> 1;
-    constexpr int NIT = (RUN / 2 + 8 + 63) / 64;
+    constexpr int NIT = ((RUN + 2 * END) / 2 + 8 + 63) / 64;
     double2 v[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; it++) {  // chunk q = the q-th 16 bytes from that boundary; LDS reads first
@@ -1368,12 +1379,19 @@ __global__ __launch_bounds__(256) void k_bc_rows(const Slab s, const KArgs a) {
   const int64_t M = s.dim[0], N = s.dim[1];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // x-rows of nodes (j, k) are walked with a stride (most rows have two Dirichlet nodes only); S3 128^3: 45 us =
-  // 4 TB/s of stores; P3 256^3: 100 us -- one wave per 144-byte row is instruction-bound there
+  // 4 TB/s of stores; P3 256^3: instruction-bound (splitting the face rows into 32-node segments over more
+  // workgroups made it 5x slower: the per-unit index arithmetic dominates)
   const int64_t nrow = (s.nsd == 3) ? N * (a.s1 - a.s0) : (a.s1 - a.s0);
-  for (int64_t row = blockIdx.x; row < nrow; row += gridDim.x) {
+  for (uint32_t row = blockIdx.x; row < (uint32_t)nrow; row += gridDim.x) {  // (nrow < 2^31: checked by the host)
   int64_t j, k;
-  if (s.nsd == 3) { j = row % N; k = a.s0 + row / N; } else { j = a.s0 + row; k = 0; }
+  if (s.nsd == 3) { const uint32_t kq = row / (uint32_t)N; j = row - kq * (uint32_t)N; k = a.s0 + kq; } else { j = a.s0 + row; k = 0; }
   const bool full = (M < 3) || is_bc_node(s, a.bc, 1, j, k);  // is an x-interior node of this row Dirichlet?
+  if (!full && a.ends) continue;  // the two end nodes of this line were written by the interior kernel (k_assemble_p3_rect)
+  // per line: neighbour counts, the node's own position among them and the Poisson valence in y and z, start of the line
+  const int cy = span1(j, N), cz = span1(k, s.dim[2]), cyz = cy * cz;
+  const int selfyz = (s.nsd == 3 ? (k > 0) : 0) * cy + (j > 0);
+  const int vyz = ((j > 0) + (j < N - 1)) * ((k - 1 >= s.els && k - 1 < s.ele) + (k >= s.els && k < s.ele));
+  double *line = a.out + (row_start(s, 0, j, k, 0) - a.base_off);
   // dof 1 (27 values per node): each half-wave takes a node of its own; otherwise one wave per node
   const int sub = (s.dof == 1) ? (lane >> 5) : 0, lw = (s.dof == 1) ? 32 : 64, ll = lane & (lw - 1);
   const int slot = (s.dof == 1) ? 2 * w + sub : w, nslot = (s.dof == 1) ? 8 : 4;
@@ -1381,16 +1399,13 @@ __global__ __launch_bounds__(256) void k_bc_rows(const Slab s, const KArgs a) {
   for (int64_t i = full ? slot : (slot == 0 ? 0 : ((slot == 1 && M > 1) ? M - 1 : M)); i < M; i += istep) {
     if (!is_bc_node(s, a.bc, i, j, k)) continue;
     double diag = a.iface ? 0.0 : 1.0;
-    if (a.bc == BC_POISSON) {
-      const int vx = (i > 0) + (i < M - 1), vy = (j > 0) + (j < N - 1);
-      const int vz = (k - 1 >= s.els && k - 1 < s.ele) + (k >= s.els && k < s.ele);
-      diag = (double)(vx * vy * vz);
-    }
-    const int cx = span1(i, M), cy = span1(j, N), cz = span1(k, s.dim[2]);
-    const int cnt = cx * cy * cz * s.dof;
+    if (a.bc == BC_POISSON) diag = (double)(((i > 0) + (i < M - 1)) * vyz);
+    const int cx = span1(i, M);
+    const int cnt = cx * cyz * s.dof;
     // position of the node itself among its neighbours
-    const int self = (((s.nsd == 3 ? (k > 0) : 0) * cy + (j > 0)) * cx + (i > 0)) * s.dof;
-    double *blk = a.out + (row_start(s, i, j, k, 0) - a.base_off);
+    const int self = (selfyz * cx + (i > 0)) * s.dof;
+    // the blocks of a line's nodes follow each other: dof^2 * cy * cz values per x-neighbour pair before node i
+    double *blk = line + (int64_t)(s.dof * s.dof * cyz) * pre1(i, M);
     int c = 0, r = ll;  // value t = c * cnt + r of the node's block
     for (int t = ll; t < s.dof * cnt; t += lw) {
       while (r >= cnt) { r -= cnt; c++; }
