@@ -1463,22 +1463,34 @@ __global__ __launch_bounds__(256) void k_check_rectilinear(const Slab s, const d
   const int64_t nrows = N * nlayers;
   const int n3 = (int)(3 * M);
   bool bad = false;
-  for (int64_t r = blockIdx.x; r < nrows; r += gridDim.x) {
-    const int64_t kl = r / N, j = r - kl * N;
-    const double *row = coords + 3 * M * r;
-    const double yref = coords[3 * (M * j) + 1], zref = coords[3 * (M * N * kl) + 2];
-    for (int t0 = threadIdx.x; t0 < n3; t0 += 4 * 256) {  // four loads in flight per lane (clamped, streamed once)
-      double v[4];
+  // CR_H x-rows per pass (rows r + h * gridDim.x): 4 * CR_H 8-byte loads per lane in flight
+  constexpr int CR_H = 4;
+  for (int64_t r = blockIdx.x; r < nrows; r += CR_H * (int64_t)gridDim.x) {
+    const double *row[CR_H];
+    double yref[CR_H], zref[CR_H];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int t = t0 + 256 * u;
-        v[u] = __builtin_nontemporal_load(&row[t < n3 ? t : n3 - 1]);
-      }
+    for (int h = 0; h < CR_H; h++) {
+      const int64_t rh = r + h * (int64_t)gridDim.x < nrows ? r + h * (int64_t)gridDim.x : r;  // (past the end: row r again)
+      const int64_t kl = rh / N, j = rh - kl * N;
+      row[h] = coords + 3 * M * rh;
+      yref[h] = coords[3 * (M * j) + 1];
+      zref[h] = coords[3 * (M * N * kl) + 2];
+    }
+    for (int t0 = threadIdx.x; t0 < n3; t0 += 4 * 256) {  // (clamped, streamed once)
+      double v[CR_H][4];
+#pragma unroll
+      for (int h = 0; h < CR_H; h++)
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int t = t0 + 256 * u;
+          v[h][u] = __builtin_nontemporal_load(&row[h][t < n3 ? t : n3 - 1]);
+        }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int t = (t0 + 256 * u < n3) ? t0 + 256 * u : n3 - 1, c = t % 3;
-        const double ref = c == 0 ? coords[t] : (c == 1 ? yref : zref);
-        bad |= v[u] != ref;
+        const double xref = coords[t];
+#pragma unroll
+        for (int h = 0; h < CR_H; h++) bad |= v[h][u] != (c == 0 ? xref : (c == 1 ? yref[h] : zref[h]));
       }
     }
   }
