@@ -175,7 +175,8 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
     if (p->fast_level == 2 && !iface && M > 2 && y1 > y0) {
       // interior nodes: 2-D row sweep (rectangles, one (E,nu) per element; verified in the kernel)
       const Box b{1, M - 1, 0, 1, y0, y1};
-      const KArgs a = make_kargs<KIND>(p, mat, bc, out, b, s0, iface);
+      KArgs a = make_kargs<KIND>(p, mat, bc, out, b, s0, iface);
+      a.ends = (bc == FEMASM_BC_E2_COMPRESSION) ? 1 : 0;  // the kernel also writes the Dirichlet rows of the columns i = 0, M-1
       dim3 grid((unsigned)((b.x1 - b.x0 + RS2_TX - 1) / RS2_TX), (unsigned)((y1 - y0 + E2W_YC - 1) / E2W_YC), 1);
       if (timed) HIPCHK(hipEventRecord(p->ev[4], p->stream));
       hipLaunchKernelGGL(k_assemble_e2_rect, grid, dim3(64), 0, p->stream, p->s, a);
@@ -188,8 +189,11 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
         p->bytes_main = 8.0 * nint * 36.0 + (aos2 ? 16.0 * 4.0 * (double)(M - 1) * (y1 - y0 + 1) : 0.0);
       }
       // the four edges of the node grid (Dirichlet columns i = 0, M-1 and the rows j = 0, N-1): brick kernel
-      int rc2 = launch_brick<KIND>(p, mat, bc, out, Box{0, 1, 0, 1, y0, y1}, s0, iface);
-      if (!rc2) rc2 = launch_brick<KIND>(p, mat, bc, out, Box{M - 1, M, 0, 1, y0, y1}, s0, iface);
+      int rc2 = 0;
+      if (!a.ends) {
+        rc2 = launch_brick<KIND>(p, mat, bc, out, Box{0, 1, 0, 1, y0, y1}, s0, iface);
+        if (!rc2) rc2 = launch_brick<KIND>(p, mat, bc, out, Box{M - 1, M, 0, 1, y0, y1}, s0, iface);
+      }
       if (!rc2 && s0 == 0) rc2 = launch_brick<KIND>(p, mat, bc, out, Box{0, M, 0, 1, 0, 1}, s0, iface);
       if (!rc2 && s1 == N && N - 1 >= s0 && N > 1) rc2 = launch_brick<KIND>(p, mat, bc, out, Box{0, M, 0, 1, N - 1, N}, s0, iface);
       return rc2;

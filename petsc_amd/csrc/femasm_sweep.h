@@ -1228,8 +1228,8 @@ constexpr int RS2_ROW = 18, RS2_NB = 36;  // values of a CSR row / of a node blo
 // ---------------------------------------------------------------------------
 constexpr int E2W_YC = 32;
 __global__ __launch_bounds__(64) void k_assemble_e2_rect(const Slab s, const KArgs a) {
-  constexpr int NB = RS2_NB, RUN = RS2_TX * NB;
-  __shared__ __attribute__((aligned(16))) double sh_stage[RUN];
+  constexpr int NB = RS2_NB, RUN = RS2_TX * NB, END = 24;  // END: values of the two rows of an x-end node (2 x 3 neighbours x 2 x 2)
+  __shared__ __attribute__((aligned(16))) double sh_stage[END + RUN + END];
   const int lane = threadIdx.x;
   const int64_t M = s.dim[0];
   const int64_t i0 = a.x0 + (int64_t)blockIdx.x * RS2_TX;
@@ -1238,6 +1238,9 @@ __global__ __launch_bounds__(64) void k_assemble_e2_rect(const Slab s, const KAr
   const int ny = (int)(yc1 - yc0);
   const int nvx = (a.x1 - i0 < RS2_TX) ? (int)(a.x1 - i0) : RS2_TX;
   const int64_t i = (lane < nvx) ? i0 + lane : i0 + nvx - 1;  // idle lanes repeat the last node
+  // a.ends (E2:877-887: the nodes i = 0 and M-1 are Dirichlet): their rows sit right before and after the interior rows
+  // of this node row; the first and last wave of the row write them with their run (unit rows), as k_assemble_p3_rect does
+  const int pre = (a.ends && i0 == 1) ? END : 0, post = (a.ends && i0 + nvx == s.dim[0] - 1) ? END : 0;
   const bool aos = a.mat_layout == 0;
   const double xm = a.coords[2 * (i - 1)], xc = a.coords[2 * i], xp = a.coords[2 * (i + 1)];
   const double Jx[2] = {0.5 * (xc - xm), 0.5 * (xp - xc)};
@@ -1334,19 +1337,25 @@ __global__ __launch_bounds__(64) void k_assemble_e2_rect(const Slab s, const KAr
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();  // the previous step's reads of the stage are done
     {
-      double2 *dst = reinterpret_cast<double2 *>(sh_stage + lane * NB);
+      double2 *dst = reinterpret_cast<double2 *>(sh_stage + pre + lane * NB);
 #pragma unroll
       for (int c = 0; c < 2; c++)
 #pragma unroll
         for (int q = 0; q < RS2_ROW / 2; q++) dst[c * (RS2_ROW / 2) + q] = make_double2(acc[c][2 * q], acc[c][2 * q + 1]);
     }
+    if (pre + post) {
+      // row c of an end node: 12 values, 1.0 at its own position (neighbour (dj, di) = (0, 0): index 2 resp. 3 of 6, times dof)
+      const int c = lane / 12, r = lane - 12 * c;
+      if (pre && lane < END) sh_stage[lane] = (r == 4 + c) ? 1.0 : 0.0;
+      if (post && lane < END) sh_stage[pre + nvx * NB + lane] = (r == 6 + c) ? 1.0 : 0.0;
+    }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    const int n = nvx * NB;
-    double *runp = a.out + (row_start(s, i0, jn, 0, 0) - a.base_off);
+    const int n = pre + nvx * NB + post;
+    double *runp = a.out + (row_start(s, i0, jn, 0, 0) - a.base_off) - pre;
     const int head = (int)((reinterpret_cast<uintptr_t>(runp) & 127) >> 3);
     const int nchunk = (head + n + 1) >> 1;
-    constexpr int NIT = (RUN / 2 + 8 + 63) / 64;
+    constexpr int NIT = ((RUN + 2 * END) / 2 + 8 + 63) / 64;
     double2 v[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
