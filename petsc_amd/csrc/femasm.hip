@@ -604,6 +604,8 @@ int femasm_scatter_map(femasm_plan *p, int64_t *map_out) {
 int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const femasm_bc *bcs, double *csr_values,
                            double *b, femasm_stats *stats) {
   if (!p) return fail(FEMASM_ERR_ARG, "null plan");
+  const bool iface_done = p->iface_done;  // consumed by this call, however it ends
+  p->iface_done = false;
   HIPCHK(hipSetDevice(p->device));
   const auto t_begin = std::chrono::steady_clock::now();
   const int bc = bcs ? bcs->kind : FEMASM_BC_NONE;
@@ -663,7 +665,7 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
 
   int rc = 0;
   if (stats) HIPCHK(hipEventRecord(p->ev[0], p->stream));  // ms_kernel_K includes the rectilinearity pre-pass
-  if (p->iface_done) {
+  if (iface_done) {
     // femasm_assemble_interface ran just before on the same inputs without reading its flags back: they carry
     // over (a broken premise or a timed-out hand-shake there is found here), and so does the verdict of its
     // rectilinearity check; the count of bad Gauss points starts again (this call integrates those elements too)
@@ -683,7 +685,7 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
       case KIND_ELASTIC: r = launch_K<KIND_ELASTIC>(p, &mloc, bc, d_vals, s.ks, s.ke, 0); break;
     }
     if (r) return r;
-    if (s.ks > 0 && !p->iface_done) {  // partial rows of node layer ks-1, owed to the rank below
+    if (s.ks > 0 && !iface_done) {  // partial rows of node layer ks-1, owed to the rank below
       switch (p->kind) {
         case KIND_POISSON: r = launch_K<KIND_POISSON>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1); break;
         case KIND_PLANE:   r = launch_K<KIND_PLANE>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1); break;
@@ -708,7 +710,7 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
       case KIND_ELASTIC: rc = launch_rhs<KIND_ELASTIC>(p, &mloc, bc, d_b, s.ks, s.ke, 0, true); break;
     }
     if (rc) return rc;
-    if (s.ks > 0 && !p->iface_done) {
+    if (s.ks > 0 && !iface_done) {
       double *sb = p->send + p->send_nnz;
       switch (p->kind) {
         case KIND_POISSON: rc = launch_rhs<KIND_POISSON>(p, &mloc, bc, sb, s.ks - 1, s.ks, 1, false); break;
