@@ -655,6 +655,24 @@ __device__ inline void row_waves_sync(unsigned *cnt, unsigned &epoch, int lane, 
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// 16-byte store of a CSR value pair in the run pattern of the level-2 kernels (consecutive lanes, whole 128-byte
+// lines), with the non-temporal hint: the values are never read back, and without the hint the kernel's dirty lines
+// are still draining from L2 when the read-bound RHS kernels start.  Measured (plain -> hint): P3 256^3 interior kernel
+// 0.82 -> 0.76 ms; S3 128^3 interior kernel unchanged, the RHS pass after it 1.04 -> 0.97 ms; E2 2048^2 interior
+// kernel 0.34 -> 0.36 ms but the RHS after it 0.19 -> 0.15 ms.  (-DFEMASM_PLAIN_K_STORES: plain stores.  The hint on a
+// per-lane row pattern, DESIGN section 3, is 8x slower: it only pays on whole lines.)
+__device__ inline void store_pair(double *p, double2 v) {
+#ifndef FEMASM_PLAIN_K_STORES
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  d2v vv;
+  vv.x = v.x;
+  vv.y = v.y;
+  __builtin_nontemporal_store(vv, reinterpret_cast<d2v *>(p));
+#else
+  *reinterpret_cast<double2 *>(p) = v;
+#endif
+}
+
 template <int KIND, int C>
 __device__ inline void rowsweep_row_wave(const Slab &s, const KArgs &a, const double2 *sh_rec, double *sh_stage,
                                          unsigned *sh_cnt, int wv, int lane, int64_t i0, int64_t j0, int64_t zc0,
@@ -717,7 +735,7 @@ __device__ inline void rowsweep_row_wave(const Slab &s, const KArgs &a, const do
 #if FEMASM_EXP == 1
               asm volatile("" ::"v"(v[it].x), "v"(v[it].y));
 #else
-              *reinterpret_cast<double2 *>(runp + s0) = v[it];
+              store_pair(runp + s0, v[it]);
 #endif
             } else if (s0 == -1) {
               runp[0] = v[it].y;
@@ -1171,7 +1189,7 @@ __global__ __launch_bounds__(64) void k_assemble_p3_rect(const Slab s, const KAr
     for (int it = 0; it < NIT; it++) {
       const int q = lane + 64 * it, s0 = 2 * q - head;
       if (q < nchunk) {
-        if (s0 >= 0 && s0 + 1 < n) *reinterpret_cast<double2 *>(runp + s0) = v[it];
+        if (s0 >= 0 && s0 + 1 < n) store_pair(runp + s0, v[it]);
         else if (s0 == -1) runp[0] = v[it].y;
         else if (s0 == n - 1) runp[s0] = v[it].x;
       }
@@ -1367,7 +1385,7 @@ __global__ __launch_bounds__(64) void k_assemble_e2_rect(const Slab s, const KAr
     for (int it = 0; it < NIT; it++) {
       const int q = lane + 64 * it, s0 = 2 * q - head;
       if (q < nchunk) {
-        if (s0 >= 0 && s0 + 1 < n) *reinterpret_cast<double2 *>(runp + s0) = v[it];
+        if (s0 >= 0 && s0 + 1 < n) store_pair(runp + s0, v[it]);
         else if (s0 == -1) runp[0] = v[it].y;
         else if (s0 == n - 1) runp[s0] = v[it].x;
       }
