@@ -80,6 +80,13 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise FileNotFoundError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; "
                                     "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        try:
+            # torch bundles a HIP runtime of its own (libamdhip64.so.7): it has to be in the process before
+            # libfemasm.so pulls in /opt/rocm's, or the process ends up with two runtimes and this library's one
+            # sees no device (found with `python __graft_entry__.py smoke`, where build() loaded the library first)
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         lib.femasm_last_error.restype = C.c_char_p
         lib.femasm_version.restype = C.c_char_p
