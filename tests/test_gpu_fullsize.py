@@ -176,3 +176,16 @@ def test_compiled_driver_on_the_c_abi_converges_at_second_order(kind):
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("L2 error ratio") == 2
+
+
+def test_build_then_smoke_in_one_process():
+    """__graft_entry__.build() loads libfemasm.so, smoke() then uses torch: the library and torch must end up on
+    one HIP runtime whatever the order (regression: the library loaded first saw no device)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("smoke: elastic3d") == 2
