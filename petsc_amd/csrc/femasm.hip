@@ -11,6 +11,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <chrono>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -228,9 +229,22 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
       }
       if (fast) {
         constexpr int TX = RowSweep<KIND>::TX, TY = RowSweep<KIND>::TY;
-        // node layers per workgroup: 16 / 32 / 64 measured within 1 % of each other at 128^3 and 256^3 (the 3-layer
-        // prologue of a workgroup costs about one step); FEMASM_ZC overrides for experiments
-        int64_t zc = 32;
+        // node layers per workgroup.  Row-sweep kernel (2 workgroups per CU resident): of 16 / 32 / 64 the one that
+        // fills the last round of resident workgroups best, weighed against the ~2-layer prologue of a workgroup
+        // (128^3: 64 -> 512 workgroups = exactly one round, 0.92 ms against 0.94 ms with 32; 96^3: 32 -> 0.47 ms against
+        // 0.70 ms with 64; 160^3: 32).  Autonomous-wave Poisson kernel: 16 (8..16 within 1 %, 32: +5 %, 64: +8 %).
+        // FEMASM_ZC overrides for experiments.
+        int64_t zc = 16;
+        if (!(KIND == KIND_POISSON && rect)) {
+          const double resident = 2.0 * p->ncu;
+          const double tiles = (double)((b.x1 - b.x0 + TX - 1) / TX) * (double)((b.y1 - b.y0 + TY - 1) / TY);
+          double best = -1.0;
+          for (int64_t c : {16, 32, 64}) {
+            const double W = tiles * (double)((z1 - z0 + c - 1) / c);
+            const double score = W / (std::ceil(W / resident) * resident) * (double)c / (double)(c + 2);
+            if (score > best) { best = score; zc = c; }
+          }
+        }
         if (const char *e = getenv("FEMASM_ZC")) zc = atoi(e) > 0 ? atoi(e) : zc;
         if (zc > 128) zc = 128;
         KArgs az = a;
