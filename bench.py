@@ -42,7 +42,38 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse "
                     "several ranks on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use GPU 0")
+    ap.add_argument("--check", action="store_true", help="after the timed steps, assemble the same GLOBAL mesh as one "
+                    "plan on this rank's GPU and report rel(K), rel(b) of this rank's slab rows against it (max over "
+                    "ranks) in the JSON line; small meshes only")
     return ap.parse_args()
+
+
+def host_cpu():
+    """Model name and core count of the host the CPU baseline runs on."""
+    model, ncpu = "unknown", os.cpu_count()
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        ncpu_avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu_avail = ncpu
+    return model, ncpu, ncpu_avail
+
+
+def _cfg1_worker(_):
+    from oracle import oracle as O
+    n = 32
+    M = n + 1
+    coords = O.uniform_coords(3, M, M, M)
+    rp, ci = O.pattern(3, 1, M, M, M)
+    t0 = time.perf_counter()
+    O.assemble_poisson3d(M, M, M, coords, rp, ci)
+    return time.perf_counter() - t0
 
 
 def cpu_baseline(workload):
@@ -81,8 +112,28 @@ def cpu_baseline(workload):
         O.bc_e2(M, M, rp, ci, K, b)
         dt = time.perf_counter() - t0
         nel, sample = n * n, "2560^2 sub-mesh (K + b + BC)"
-    return {"value": nel / dt, "unit": "elements/s", "cores": 1, "kind": "port", "sample": sample,
-            "seconds": round(dt, 3)}
+    out = {"value": nel / dt, "unit": "elements/s", "cores": 1, "kind": "port", "sample": sample,
+           "seconds": round(dt, 3)}
+    # BASELINE config 1 in full (FEM_poisson3D 32^3, serial: the reference's own CPU-runnable case, K + b with the
+    # in-loop Dirichlet rows), then the same case on every core this process may use at once (independent copies,
+    # one per core: a context figure for "all cores", the reference itself is serial), and the host CPU
+    t1 = _cfg1_worker(0)
+    model, ncpu, navail = host_cpu()
+    out["config1_poisson3d_32"] = {"value": 32 ** 3 / t1, "unit": "elements/s", "cores": 1, "seconds": round(t1, 4),
+                                   "sample": "32^3 in full"}
+    nw = max(1, min(navail, 16))
+    try:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(nw) as pool:
+            t0 = time.perf_counter()
+            pool.map(_cfg1_worker, range(nw))
+            wall = time.perf_counter() - t0
+        out["all_cores_context"] = {"value": nw * 32 ** 3 / wall, "unit": "elements/s", "cores": nw,
+                                    "sample": f"{nw} independent copies of config 1, one per core"}
+    except Exception as exc:  # a box that forbids fork: the serial figure stands alone
+        out["all_cores_context"] = {"error": str(exc)}
+    out["host_cpu"] = {"model": model, "logical_cpus": ncpu, "usable_cpus": navail}
+    return out
 
 
 def measured_traffic(wl, nel, world, args):
@@ -183,6 +234,8 @@ def main():
         if world > 1:
             # the rows owed to the rank below first, so that their transfer overlaps the bulk of the assembly
             plan.assemble_interface(material=material, stride=stride, bc=bc, E=E, nu=nu, e_ks=els)
+            if args.backend != "nccl":
+                plan.sync()  # gloo reads the send tensor from the host side: no stream ordering, so wait for the kernels
             reqs = slab.exchange_interface_start(send if rank > 0 else None, recv if rank < world - 1 else None,
                                                  rank, world)
         st = plan.assemble_system(vals, b, material=material, stride=stride, bc=bc, E=E, nu=nu, e_ks=els,
@@ -218,11 +271,44 @@ def main():
     dt = float(tmax.item())
     nel_total = float(nel_local.item())
 
+    check = None
+    if args.check:
+        # the same GLOBAL mesh as one plan on this rank's GPU; this rank's slab rows against the global system's rows
+        gco = synth.uniform_coords(nsd, M, N, P, device=dev)
+        if args.perturb:
+            gco = synth.perturb_coords(gco, nsd, M, N, P)
+        gplan = F.Plan(kind, M, N, P, coords=gco, device=local_rank)
+        gmat = None
+        if material is not None:
+            gmat = torch.empty(gplan.nel * stride, dtype=torch.float64, device=dev)
+            gplan.fill_properties(gmat, E, nu, stride)
+        gv = torch.empty(gplan.nnz, dtype=torch.float64, device=dev)
+        gb = torch.empty(gplan.nrows, dtype=torch.float64, device=dev)
+        gplan.assemble_system(gv, gb, material=gmat, stride=stride, bc=bc, E=E, nu=nu)
+        lo = slab.layer_nnz(nsd, dof, M, N, P, 0, ks)
+        plane = (M * N if nsd == 3 else M) * dof
+        relK = float(torch.linalg.norm(vals - gv[lo:lo + plan.nnz]) / torch.linalg.norm(gv[lo:lo + plan.nnz]))
+        relb = 0.0
+        if b is not None:
+            gbs = gb[plane * ks:plane * ke]
+            relb = float(torch.linalg.norm(b - gbs) / torch.linalg.norm(gbs))
+        cmax = torch.tensor([relK, relb], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
+        check = {"rel_K": float(cmax[0].item()), "rel_b": float(cmax[1].item()),
+                 "against": "one-plan assembly of the global mesh, this rank's rows, max over ranks"}
+        gplan.close()
+
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
         k_avg_ms = sum(k_ms) / len(k_ms)        # all stiffness kernels (interior + Dirichlet shell rows)
         main_avg_ms = sum(main_ms) / len(main_ms)  # the dominant kernel alone, HIP events on its stream
-        achieved = st.bytes_main / (main_avg_ms * 1e-3) / 1e9
+        if main_avg_ms > 0.0 and st.bytes_main > 0.0:
+            achieved = st.bytes_main / (main_avg_ms * 1e-3) / 1e9
+        elif k_avg_ms > 0.0:  # no interior kernel was launched (a mesh or slab without interior nodes): all of K
+            achieved = st.bytes_K / (k_avg_ms * 1e-3) / 1e9
+        else:
+            achieved = None
         level = plan.fast_path()
         if wl == "elastic2d":
             kernel = "k_assemble_e2_rect" if level == 2 else "k_assemble_rows<PLANE_STRAIN2D>"
@@ -251,6 +337,9 @@ def main():
                             f"{' (general geometry)' if args.perturb else ' (uniform DMDA coordinates)'}, "
                             f"K + b + Dirichlet rows{' (K only)' if args.k_only else ''}",
                 "global_elements": int(nel_total),
+                "global_mesh": ("x".join(str(v - 1) for v in ((M, N, P) if nsd == 3 else (M, N))) + " elements, "
+                                + ("fixed (strong scaling)" if args.strong else
+                                   f"{nel} per direction per GPU stacked along the slab direction (weak scaling)")),
                 "rows_per_gpu": int(st.nrows),
                 "nnz_per_gpu": int(st.nnz),
                 "material": "uniform" if material is None else f"AoS GaussPointCoefficients stride {stride}",
@@ -263,7 +352,7 @@ def main():
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
+                "frac": None if achieved is None else achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": st.bytes_main,
                 "avg_launch_ms": main_avg_ms,
@@ -273,9 +362,11 @@ def main():
         }
         # the whole K assembly of this rank (every stiffness kernel incl. Dirichlet rows and the pre-pass) against
         # SURVEY 8(d)'s formula (femasm_stats.bytes_K = 8 nnz + 8 NSD nnodes + 16 NGP nel [E,nu per Gauss point])
-        k_gbs = st.bytes_K / (k_avg_ms * 1e-3) / 1e9
+        k_gbs = st.bytes_K / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0.0 else None
         out["k_assembly"] = {"algorithmic_bytes": st.bytes_K, "ms": k_avg_ms, "achieved_GBps": k_gbs,
-                             "frac": k_gbs / HBM_PEAK_GBS}
+                             "frac": None if k_gbs is None else k_gbs / HBM_PEAK_GBS}
+        if check is not None:
+            out["check"] = check
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(out), flush=True)

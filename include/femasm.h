@@ -65,10 +65,13 @@ typedef struct {
  * 0.57735026919 and unit weights (P3:152-174, E2:124-135, S3:229-289). */
 typedef struct { int32_t ngp; int32_t rule; } femasm_quad;
 
-/* Dirichlet boundary conditions (A10, A11).  Rows only, diagonal 1.0, no column
- * elimination, no RHS lifting -- exactly MatZeroRows(A,n,ids,1.0,0,0) /
- * the _ZERO_ROW_i macro.  The zeroed rows keep their slots in the DMDA pattern
- * (explicit zeros); femasm_compress_bc_rows() gives PETSc's truncated form. */
+/* Dirichlet boundary conditions (A10, A11).  Rows only, no column elimination, no RHS
+ * lifting.  Elastic kinds: diagonal 1.0, exactly MatZeroRows(A,n,ids,1.0,0,0).  Poisson:
+ * the _ZERO_ROW_i macro acts on every ELEMENT matrix before ADD_VALUES (P3:286-290,
+ * 328-340), so the assembled diagonal of a boundary row is the number of assembled
+ * elements sharing the node (1, 2 or 4), not 1.  The zeroed rows keep their slots in the
+ * DMDA pattern (explicit zeros); femasm_compress_bc_rows() gives PETSc's truncated
+ * form for the elastic kinds (the Poisson driver has no MatZeroRows step). */
 enum {
   FEMASM_BC_NONE = 0,
   FEMASM_BC_POISSON_INLOOP = 1,  /* P3:286-290, 328-338, 624-630                       */
@@ -163,7 +166,8 @@ int femasm_interface_apply(femasm_plan *plan, const femasm_bc *bc, double *csr_v
 
 /* PETSc's default MatZeroRows storage (keepnonzeropattern off): zeroed rows keep only
  * their diagonal and the CSR arrays are recompressed.  Outputs HOST or DEVICE,
- * sized like the inputs; *nnz_out receives the new count. */
+ * sized like the inputs; *nnz_out receives the new count.  Elastic BC kinds only
+ * (FEMASM_BC_POISSON_INLOOP is rejected: P3 never calls MatZeroRows). */
 int femasm_compress_bc_rows(femasm_plan *plan, const femasm_bc *bc, const double *csr_values,
                             int64_t *rowptr_out, int32_t *colidx_out, double *values_out, int64_t *nnz_out);
 
@@ -197,6 +201,15 @@ int femasm_fill_properties(femasm_plan *plan, double E, double nu, int32_t strid
  * HOST or DEVICE.  sums[0] = sum of the L2 integrals, sums[1] = of the H1 integrals; the caller adds the ranks'
  * sums (MPI_Allreduce, P3:510-513) and takes the square roots; h = 1/(M-1).  3-D kinds only. */
 int femasm_error_integrals(femasm_plan *plan, const double *u, double sums[2]);
+
+/* No counterpart in the reference.  femasm_error_integrals for callers that cannot allocate: code under HIP graph
+ * capture, tight solver loops, harnesses that forbid hipMalloc.  Same kernels and the same bits; the per-workgroup
+ * partial sums live in a static device array inside the library (1 MiB per GPU, held until the process ends) instead
+ * of plan-owned memory, u and sums are DEVICE pointers (sums[2] is written in stream order, nothing is copied back
+ * and the call does not wait), and no hipMalloc / hipFree / host copy happens.  Limit: at most 16 777 216 elements
+ * (256^3) in the plan's slab, larger slabs are rejected with FEMASM_ERR_ARG.  All plans of one GPU share the one
+ * array: calls that overlap on a GPU (different streams or host threads) race -- order them. */
+int femasm_error_integrals_static(femasm_plan *plan, const double *u, double *sums);
 
 /* SURVEY 8(f) row N2, the step after the path: landing K in a (device-resident) PETSc Mat without the host.
  * Either hand femasm_assemble_system the Mat's own value array (MatSeqAIJGetCSRAndMemType /

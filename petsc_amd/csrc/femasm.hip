@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -56,6 +57,35 @@ bool is_device_ptr(const void *p) {
 
 inline unsigned nblk(int64_t n, int per = 256) { return (unsigned)((n + per - 1) / per); }
 
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// Static device scratch of the one entry point that allocates nothing (femasm_error_integrals_static): the
+// per-workgroup partial sums of k_error_integrals, 2 doubles per workgroup of 256 elements.  Every GPU the
+// library runs on holds its own copy of this array (1 MiB) until the process ends.  In host code the NAME below is
+// only a stand-in for HIP_SYMBOL(): the device address is looked up once per device (static_scratch_for) and that
+// pointer is what kernels and memsets get.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int64_t STATIC_NB_MAX = 65536;  // workgroups -> at most 256 * 65536 = 16 777 216 elements (256^3) per slab
+static __device__ __align__(256) double scratch[2 * STATIC_NB_MAX];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mu;
+double *g_scratch_ptr[MAX_DEVICES] = {};
+// address of THIS device's copy of `scratch`; called with `device` current (femasm_plan_create), once per device
+int static_scratch_for(int device, double **out) {
+  if (device < 0 || device >= MAX_DEVICES) return fail(FEMASM_ERR_ARG, "device %d beyond the %d this build tracks", device, MAX_DEVICES);
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (!g_scratch_ptr[device]) {
+    double *ptr = nullptr;
+    HIPCHK(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) return fail(FEMASM_ERR_HIP, "hipGetSymbolAddress(scratch) returned a null address on device %d", device);
+    g_scratch_ptr[device] = ptr;
+  }
+  if (out) *out = g_scratch_ptr[device];
+  return FEMASM_OK;
+}
 }  // namespace
 
 struct femasm_plan {
@@ -100,7 +130,14 @@ struct femasm_plan {
 
   // staging for host-side callers
   double *stage_vals = nullptr, *stage_b = nullptr, *stage_gp = nullptr;
-  int64_t stage_gp_count = 0;
+  int64_t stage_gp_count = 0;          // doubles allocated in stage_gp (grown, never shrunk)
+  const double *gp_cur = nullptr;      // DEVICE material array of the call in progress (staged copy or the caller's pointer),
+                                       // set by every entry point that launches kernels: never carried from call to call
+  double *partial = nullptr;           // partial sums of femasm_error_integrals / femasm_coord_moments (grown on demand)
+  int64_t partial_count = 0;
+  double *stage_u = nullptr;           // femasm_error_integrals: device copy of a host solution vector
+  int64_t stage_u_count = 0;
+  double *static_scratch = nullptr;    // this device's copy of the file-scope `scratch` array (femasm_error_integrals_static)
 };
 
 namespace {
@@ -129,7 +166,7 @@ KArgs make_kargs(femasm_plan *p, const femasm_material *mat, int bc, double *out
   using T = Traits<KIND>;
   KArgs a{};
   a.coords = p->coords;
-  a.gp = (mat && mat->layout == FEMASM_MAT_AOS) ? (p->stage_gp ? p->stage_gp : mat->gp) : nullptr;
+  a.gp = (mat && mat->layout == FEMASM_MAT_AOS) ? p->gp_cur : nullptr;
   a.out = out;
   a.bad = p->bad;
   a.base_off = (T::NSD == 3) ? row_start(p->s, 0, 0, base_s0, 0) : row_start(p->s, 0, base_s0, 0, 0);
@@ -329,7 +366,7 @@ int launch_rhs(femasm_plan *p, const femasm_material *mat, int bc, double *out, 
   if (nel < 0) nel = p->nel;
   RArgs a{};
   a.coords = p->coords;
-  a.gp = (mat && mat->layout == FEMASM_MAT_AOS) ? (p->stage_gp ? p->stage_gp : mat->gp) : nullptr;
+  a.gp = (mat && mat->layout == FEMASM_MAT_AOS) ? p->gp_cur : nullptr;
   a.elemF = p->elemF;
   a.out = out;
   a.cke = p->cke;
@@ -447,6 +484,10 @@ int femasm_plan_create(const femasm_mesh *mesh, const femasm_quad *quad, int dev
   if (!p) return fail(FEMASM_ERR_NOMEM, "out of host memory");
   p->device = device;
   p->kind = mesh->problem;
+  if (int rcs = static_scratch_for(device, &p->static_scratch)) {  // set-up of the no-allocation entry point, once per device
+    delete p;
+    return rcs;
+  }
   Slab &s = p->s;
   s.dim[0] = M; s.dim[1] = N; s.dim[2] = P;
   s.ks = mesh->ks; s.ke = mesh->ke; s.cks = mesh->cks;
@@ -551,7 +592,7 @@ int femasm_plan_destroy(femasm_plan *p) {
   }
 #endif
   void *bufs[] = {p->coords_dev, p->rowptr, p->colidx, p->elemF, p->own_send ? p->send : nullptr,
-                  p->own_recv ? p->recv : nullptr, p->bad, p->stage_vals, p->stage_b, p->stage_gp, p->lines};
+                  p->own_recv ? p->recv : nullptr, p->bad, p->stage_vals, p->stage_b, p->stage_gp, p->lines, p->partial, p->stage_u};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   if (p->flags_host) (void)hipHostFree(p->flags_host);
@@ -665,14 +706,21 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
     if (!p->stage_b) HIPCHK(hipMalloc(&p->stage_b, (size_t)p->nrows * sizeof(double)));
     d_b = p->stage_b;
   }
-  if (p->stage_gp) { (void)hipFree(p->stage_gp); p->stage_gp = nullptr; }
-  if (mloc.layout == FEMASM_MAT_AOS && p->kind != KIND_POISSON && !is_device_ptr(mloc.gp)) {
+  p->gp_cur = (mloc.layout == FEMASM_MAT_AOS && p->kind != KIND_POISSON) ? mloc.gp : nullptr;
+  if (p->gp_cur && !is_device_ptr(mloc.gp)) {
     const int64_t eplane = (nsd == 3) ? (s.dim[0] - 1) * (s.dim[1] - 1) : (s.dim[0] - 1);
     const int64_t cnt = eplane * (s.ele - mloc.e_ks) * mloc.stride;
     if (cnt > 0) {
-      HIPCHK(hipMalloc(&p->stage_gp, cnt * sizeof(double)));
+      if (cnt > p->stage_gp_count) {  // plan-owned, reallocated only when the required size grows
+        if (p->stage_gp) (void)hipFree(p->stage_gp);
+        p->stage_gp = nullptr;
+        p->stage_gp_count = 0;
+        HIPCHK(hipMalloc(&p->stage_gp, cnt * sizeof(double)));
+        p->stage_gp_count = cnt;
+      }
       HIPCHK(hipMemcpyAsync(p->stage_gp, mloc.gp, cnt * sizeof(double), hipMemcpyHostToDevice, p->stream));
       HIPCHK(hipStreamSynchronize(p->stream));
+      p->gp_cur = p->stage_gp;
     }
   }
   ms_staging += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -840,6 +888,7 @@ int femasm_assemble_interface(femasm_plan *p, const femasm_material *mat, const 
   } else {
     mloc.layout = FEMASM_MAT_UNIFORM;
   }
+  p->gp_cur = (mloc.layout == FEMASM_MAT_AOS && p->kind != KIND_POISSON) ? mloc.gp : nullptr;  // device memory (checked above)
   const Slab &s = p->s;
   if (s.ks == 0) { p->iface_done = false; return FEMASM_OK; }  // lowest slab: nothing is owed, nothing carries over
   if (!p->send) return fail(FEMASM_ERR_ARG, "no send buffer");
@@ -918,7 +967,8 @@ int femasm_apply_operator(femasm_plan *p, const femasm_material *mat, const fema
   const Slab &s = p->s;
   RArgs a{};
   a.coords = p->coords;
-  a.gp = (mloc.layout == FEMASM_MAT_AOS) ? mloc.gp : nullptr;
+  p->gp_cur = (mloc.layout == FEMASM_MAT_AOS) ? mloc.gp : nullptr;
+  a.gp = p->gp_cur;
   a.elemF = p->elemF;
   a.cke = p->cke;
   a.nel = p->nel;
@@ -983,6 +1033,17 @@ int femasm_fill_properties(femasm_plan *p, double E, double nu, int32_t stride, 
   return FEMASM_OK;
 }
 
+// plan-owned scratch, grown on demand (femasm_error_integrals, femasm_coord_moments): no allocation per call
+static int grow(double **buf, int64_t *have, int64_t need) {
+  if (need <= *have) return FEMASM_OK;
+  if (*buf) (void)hipFree(*buf);
+  *buf = nullptr;
+  *have = 0;
+  HIPCHK(hipMalloc(buf, (size_t)need * sizeof(double)));
+  *have = need;
+  return FEMASM_OK;
+}
+
 int femasm_error_integrals(femasm_plan *p, const double *u, double sums[2]) {
   if (!p || !u || !sums) return fail(FEMASM_ERR_ARG, "null argument");
   if (p->kind == KIND_PLANE) return fail(FEMASM_ERR_ARG, "the reference has no error norms for the 2-D driver");
@@ -992,15 +1053,14 @@ int femasm_error_integrals(femasm_plan *p, const double *u, double sums[2]) {
   const Slab &s = p->s;
   const int64_t nghost = (int64_t)s.dim[0] * s.dim[1] * (p->cke - s.cks) * s.dof;  // u has the layers of coords
   const double *d_u = u;
-  double *stage = nullptr;
   if (!is_device_ptr(u)) {
-    HIPCHK(hipMalloc(&stage, nghost * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(stage, u, nghost * sizeof(double), hipMemcpyHostToDevice, p->stream));
-    d_u = stage;
+    if (int rc = grow(&p->stage_u, &p->stage_u_count, nghost)) return rc;
+    HIPCHK(hipMemcpyAsync(p->stage_u, u, nghost * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    d_u = p->stage_u;
   }
   const int64_t nb = (p->nel + 255) / 256;
-  double *partial = nullptr;
-  HIPCHK(hipMalloc(&partial, (2 * nb + 2) * sizeof(double)));
+  if (int rc = grow(&p->partial, &p->partial_count, 2 * nb + 2)) return rc;
+  double *partial = p->partial;
   if (p->kind == KIND_POISSON)
     hipLaunchKernelGGL(k_error_integrals<KIND_POISSON>, dim3((unsigned)nb), dim3(256), 0, p->stream, s, p->coords, d_u,
                        p->nel, partial);
@@ -1008,12 +1068,43 @@ int femasm_error_integrals(femasm_plan *p, const double *u, double sums[2]) {
     hipLaunchKernelGGL(k_error_integrals<KIND_ELASTIC>, dim3((unsigned)nb), dim3(256), 0, p->stream, s, p->coords, d_u,
                        p->nel, partial);
   hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, p->stream, partial, nb, partial + 2 * nb);
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpyAsync(sums, partial + 2 * nb, 2 * sizeof(double), hipMemcpyDeviceToHost, p->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
-  (void)hipFree(partial);
-  if (stage) (void)hipFree(stage);
-  if (e != hipSuccess) return fail(FEMASM_ERR_HIP, "femasm_error_integrals: %s", hipGetErrorString(e));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(sums, partial + 2 * nb, 2 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  return FEMASM_OK;
+}
+
+// The entry point that allocates nothing: femasm_error_integrals for callers that cannot call hipMalloc (HIP graph
+// capture, tight solver loops).  Same two kernels; the partial sums go to this device's copy of the static `scratch`
+// array (address taken once per device in femasm_plan_create), the result to a DEVICE pointer, and nothing is copied
+// back or waited for: no hipMalloc, hipFree, host copy or synchronisation happens here.
+// Nothing in the scratch has to start at zero: k_error_integrals writes both sums of every workgroup 0 .. nb-1 before
+// k_sum_partials, launched behind it on the same stream, reads exactly those nb pairs.
+int femasm_error_integrals_static(femasm_plan *p, const double *u, double *sums) {
+  if (!p || !u || !sums) return fail(FEMASM_ERR_ARG, "null argument");
+  if (p->kind == KIND_PLANE) return fail(FEMASM_ERR_ARG, "the reference has no error norms for the 2-D driver");
+  HIPCHK(hipSetDevice(p->device));
+  if (!is_device_ptr(u) || !is_device_ptr(sums))
+    return fail(FEMASM_ERR_ARG, "femasm_error_integrals_static takes DEVICE pointers (u and sums): staging would allocate");
+  const int64_t nb = (p->nel + 255) / 256;
+  if (nb > STATIC_NB_MAX)
+    return fail(FEMASM_ERR_ARG, "femasm_error_integrals_static: %lld elements exceed the static scratch (at most %lld per slab); "
+                "use femasm_error_integrals", (long long)p->nel, (long long)(256 * STATIC_NB_MAX));
+  double *partial = p->static_scratch;  // the looked-up device address, never the array's name
+  if (!partial) return fail(FEMASM_ERR_HIP, "static scratch of device %d was not set up", p->device);
+  if (p->nel <= 0) {
+    HIPCHK(hipMemsetAsync(sums, 0, 2 * sizeof(double), p->stream));
+    return FEMASM_OK;
+  }
+  const Slab &s = p->s;
+  if (p->kind == KIND_POISSON)
+    hipLaunchKernelGGL(k_error_integrals<KIND_POISSON>, dim3((unsigned)nb), dim3(256), 0, p->stream, s, p->coords, u,
+                       p->nel, partial);
+  else
+    hipLaunchKernelGGL(k_error_integrals<KIND_ELASTIC>, dim3((unsigned)nb), dim3(256), 0, p->stream, s, p->coords, u,
+                       p->nel, partial);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, p->stream, partial, nb, sums);
+  HIPCHK(hipGetLastError());
   return FEMASM_OK;
 }
 
@@ -1067,6 +1158,11 @@ int femasm_compress_bc_rows(femasm_plan *p, const femasm_bc *bcs, const double *
     return fail(FEMASM_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(p->device));
   const int bc = bcs ? bcs->kind : FEMASM_BC_NONE;
+  // MatZeroRows is what the elastic drivers call (E2:794-799, S3:1513-1518); the Poisson driver never does: its
+  // boundary rows are assembled (diagonal = number of elements sharing the node, P3:286-340) and stay in the pattern
+  if (bc == FEMASM_BC_POISSON_INLOOP)
+    return fail(FEMASM_ERR_ARG, "femasm_compress_bc_rows: the Poisson driver has no MatZeroRows step (its Dirichlet "
+                "rows are assembled in the element loop, diagonal = element valence)");
   const bool in_dev = is_device_ptr(csr_values);
   const bool out_dev = is_device_ptr(rowptr_out) && is_device_ptr(colidx_out) && is_device_ptr(values_out);
   const bool out_host = !is_device_ptr(rowptr_out) && !is_device_ptr(colidx_out) && !is_device_ptr(values_out);
@@ -1168,15 +1264,13 @@ int femasm_coord_moments(femasm_plan *p, double mom[10]) {
   if (nown <= 0) return FEMASM_OK;
   int64_t nb = (nown + 255) / 256;
   if (nb > 1024) nb = 1024;
-  double *partial = nullptr;
-  HIPCHK(hipMalloc(&partial, (10 * nb + 10) * sizeof(double)));
+  if (int rc = grow(&p->partial, &p->partial_count, 10 * nb + 10)) return rc;
+  double *partial = p->partial;
   hipLaunchKernelGGL(k_coord_moments, dim3((unsigned)nb), dim3(256), 0, p->stream, s, p->coords, nown, partial);
   hipLaunchKernelGGL(k_sum_rows10, dim3(1), dim3(64), 0, p->stream, partial, nb, partial + 10 * nb);
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpyAsync(mom, partial + 10 * nb, 10 * sizeof(double), hipMemcpyDeviceToHost, p->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
-  (void)hipFree(partial);
-  if (e != hipSuccess) return fail(FEMASM_ERR_HIP, "femasm_coord_moments: %s", hipGetErrorString(e));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(mom, partial + 10 * nb, 10 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  HIPCHK(hipStreamSynchronize(p->stream));
   return FEMASM_OK;
 }
 
@@ -1253,13 +1347,13 @@ int femasm_zero_rows(femasm_plan *p, int64_t n, const int64_t *rows, const doubl
   int64_t *d_rows = const_cast<int64_t *>(rows);
   double *d_vals = const_cast<double *>(vals);
   bool own_rows = false, own_vals = false;
-  if (!is_device_ptr(rows)) {
-    HIPCHK(hipMalloc(&d_rows, n * sizeof(int64_t)));
-    own_rows = true;
-    HIPCHK(hipMemcpyAsync(d_rows, rows, n * sizeof(int64_t), hipMemcpyHostToDevice, p->stream));
-  }
   hipError_t e = hipSuccess;
-  if (vals && !is_device_ptr(vals)) {
+  if (!is_device_ptr(rows)) {
+    HIPCHK(hipMalloc(&d_rows, n * sizeof(int64_t)));  // (nothing else is held yet)
+    own_rows = true;
+    e = hipMemcpyAsync(d_rows, rows, n * sizeof(int64_t), hipMemcpyHostToDevice, p->stream);
+  }
+  if (e == hipSuccess && vals && !is_device_ptr(vals)) {
     e = hipMalloc(&d_vals, n * sizeof(double));
     if (e == hipSuccess) {
       own_vals = true;

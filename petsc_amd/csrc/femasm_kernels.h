@@ -156,6 +156,24 @@ __device__ inline void scaled_coefs(double E, double nu, double wJ, double &d11,
 
 // 3x3 Jacobian, its inverse and determinant in the reference's order (A3, A4)
 struct Jac3 { double iJ[3][3]; double det; };
+// closed-form inverse (shared products t4 ... t14, t17 = 1/det: P3:86-107, S3:162-183) and the determinant by its
+// own six-term formula (P3:143, S3:220) -- the ONE place these are written out; every kernel calls this
+__device__ inline void inv3_ref(const double (&J)[3][3], double (&iJ)[3][3], double &det) {
+  const double t4 = J[2][0] * J[0][1], t6 = J[2][0] * J[0][2], t8 = J[1][0] * J[0][1];
+  const double t10 = J[1][0] * J[0][2], t12 = J[0][0] * J[1][1], t14 = J[0][0] * J[1][2];
+  const double t17 = 1.0 / (t4 * J[1][2] - t6 * J[1][1] - t8 * J[2][2] + t10 * J[2][1] + t12 * J[2][2] - t14 * J[2][1]);
+  iJ[0][0] = (J[1][1] * J[2][2] - J[1][2] * J[2][1]) * t17;
+  iJ[0][1] = -(J[0][1] * J[2][2] - J[0][2] * J[2][1]) * t17;
+  iJ[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * t17;
+  iJ[1][0] = -(-J[2][0] * J[1][2] + J[1][0] * J[2][2]) * t17;
+  iJ[1][1] = (-t6 + J[0][0] * J[2][2]) * t17;
+  iJ[1][2] = -(-t10 + t14) * t17;
+  iJ[2][0] = (-J[2][0] * J[1][1] + J[1][0] * J[2][1]) * t17;
+  iJ[2][1] = -(-t4 + J[0][0] * J[2][1]) * t17;
+  iJ[2][2] = (-t8 + t12) * t17;
+  det = J[0][0] * J[1][1] * J[2][2] - J[0][0] * J[1][2] * J[2][1] - J[1][0] * J[0][1] * J[2][2] +
+        J[1][0] * J[0][2] * J[2][1] + J[2][0] * J[0][1] * J[1][2] - J[2][0] * J[0][2] * J[1][1];
+}
 __device__ inline Jac3 jac3(const double (*G)[8], const double *xc /*[8][3]*/) {
   double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
 #pragma unroll
@@ -165,20 +183,7 @@ __device__ inline Jac3 jac3(const double (*G)[8], const double *xc /*[8][3]*/) {
 #pragma unroll
       for (int c = 0; c < 3; c++) J[r][c] = J[r][c] + G[r][n] * xc[3 * n + c];
   Jac3 o;
-  const double t4 = J[2][0] * J[0][1], t6 = J[2][0] * J[0][2], t8 = J[1][0] * J[0][1];
-  const double t10 = J[1][0] * J[0][2], t12 = J[0][0] * J[1][1], t14 = J[0][0] * J[1][2];
-  const double t17 = 1.0 / (t4 * J[1][2] - t6 * J[1][1] - t8 * J[2][2] + t10 * J[2][1] + t12 * J[2][2] - t14 * J[2][1]);
-  o.iJ[0][0] = (J[1][1] * J[2][2] - J[1][2] * J[2][1]) * t17;
-  o.iJ[0][1] = -(J[0][1] * J[2][2] - J[0][2] * J[2][1]) * t17;
-  o.iJ[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * t17;
-  o.iJ[1][0] = -(-J[2][0] * J[1][2] + J[1][0] * J[2][2]) * t17;
-  o.iJ[1][1] = (-t6 + J[0][0] * J[2][2]) * t17;
-  o.iJ[1][2] = -(-t10 + t14) * t17;
-  o.iJ[2][0] = (-J[2][0] * J[1][1] + J[1][0] * J[2][1]) * t17;
-  o.iJ[2][1] = -(-t4 + J[0][0] * J[2][1]) * t17;
-  o.iJ[2][2] = (-t8 + t12) * t17;
-  o.det = J[0][0] * J[1][1] * J[2][2] - J[0][0] * J[1][2] * J[2][1] - J[1][0] * J[0][1] * J[2][2] +
-          J[1][0] * J[0][2] * J[2][1] + J[2][0] * J[0][1] * J[1][2] - J[2][0] * J[0][2] * J[1][1];
+  inv3_ref(J, o.iJ, o.det);
   return o;
 }
 __device__ inline double det3_only(const double (*G)[8], const double *xc) {

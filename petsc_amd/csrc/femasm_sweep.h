@@ -229,21 +229,8 @@ __global__ __launch_bounds__(256, 2) void k_assemble_sweep(const Slab s, const K
           J[rr][2] = J[rr][2] + G[rr][n] * x2;
         }
       }
-      double iJ[3][3];
-      const double t4 = J[2][0] * J[0][1], t6 = J[2][0] * J[0][2], t8 = J[1][0] * J[0][1];
-      const double t10 = J[1][0] * J[0][2], t12 = J[0][0] * J[1][1], t14 = J[0][0] * J[1][2];
-      const double t17 = 1.0 / (t4 * J[1][2] - t6 * J[1][1] - t8 * J[2][2] + t10 * J[2][1] + t12 * J[2][2] - t14 * J[2][1]);
-      iJ[0][0] = (J[1][1] * J[2][2] - J[1][2] * J[2][1]) * t17;
-      iJ[0][1] = -(J[0][1] * J[2][2] - J[0][2] * J[2][1]) * t17;
-      iJ[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * t17;
-      iJ[1][0] = -(-J[2][0] * J[1][2] + J[1][0] * J[2][2]) * t17;
-      iJ[1][1] = (-t6 + J[0][0] * J[2][2]) * t17;
-      iJ[1][2] = -(-t10 + t14) * t17;
-      iJ[2][0] = (-J[2][0] * J[1][1] + J[1][0] * J[2][1]) * t17;
-      iJ[2][1] = -(-t4 + J[0][0] * J[2][1]) * t17;
-      iJ[2][2] = (-t8 + t12) * t17;
-      const double det = J[0][0] * J[1][1] * J[2][2] - J[0][0] * J[1][2] * J[2][1] - J[1][0] * J[0][1] * J[2][2] +
-                         J[1][0] * J[0][2] * J[2][1] + J[2][0] * J[0][1] * J[1][2] - J[2][0] * J[0][2] * J[1][1];
+      double iJ[3][3], det;
+      inv3_ref(J, iJ, det);
       const double wJ = 1.0 * det;
       if (!(wJ > 0.0)) atomicAdd(a.bad, 1ULL);
       // gradient component c = 3*n + k of node n, direction k
@@ -426,21 +413,8 @@ __global__ __launch_bounds__(256, 2) void k_assemble_sweep_p3(const Slab s, cons
             J[rr][2] = J[rr][2] + G[rr][n] * x2;
           }
         }
-        double iJ[3][3];
-        const double t4 = J[2][0] * J[0][1], t6 = J[2][0] * J[0][2], t8 = J[1][0] * J[0][1];
-        const double t10 = J[1][0] * J[0][2], t12 = J[0][0] * J[1][1], t14 = J[0][0] * J[1][2];
-        const double t17 = 1.0 / (t4 * J[1][2] - t6 * J[1][1] - t8 * J[2][2] + t10 * J[2][1] + t12 * J[2][2] - t14 * J[2][1]);
-        iJ[0][0] = (J[1][1] * J[2][2] - J[1][2] * J[2][1]) * t17;
-        iJ[0][1] = -(J[0][1] * J[2][2] - J[0][2] * J[2][1]) * t17;
-        iJ[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * t17;
-        iJ[1][0] = -(-J[2][0] * J[1][2] + J[1][0] * J[2][2]) * t17;
-        iJ[1][1] = (-t6 + J[0][0] * J[2][2]) * t17;
-        iJ[1][2] = -(-t10 + t14) * t17;
-        iJ[2][0] = (-J[2][0] * J[1][1] + J[1][0] * J[2][1]) * t17;
-        iJ[2][1] = -(-t4 + J[0][0] * J[2][1]) * t17;
-        iJ[2][2] = (-t8 + t12) * t17;
-        const double det = J[0][0] * J[1][1] * J[2][2] - J[0][0] * J[1][2] * J[2][1] - J[1][0] * J[0][1] * J[2][2] +
-                           J[1][0] * J[0][2] * J[2][1] + J[2][0] * J[0][1] * J[1][2] - J[2][0] * J[0][2] * J[1][1];
+        double iJ[3][3], det;
+        inv3_ref(J, iJ, det);
         const double wJ = 1.0 * det;
         if (!(wJ > 0.0)) atomicAdd(a.bad, 1ULL);
         double Cm[3][3];
@@ -944,22 +918,8 @@ __global__ __launch_bounds__(64 * (3 + RowSweep<KIND>::NRW), 2) void k_assemble_
           dst[2 * NS] = make_double2(0.0, (i2 * i2) * wJ);
           return;
         }
-        double iJ[3][3];
-        const double t4 = J[2][0] * J[0][1], t6 = J[2][0] * J[0][2], t8 = J[1][0] * J[0][1];
-        const double t10 = J[1][0] * J[0][2], t12 = J[0][0] * J[1][1], t14 = J[0][0] * J[1][2];
-        const double t17 =
-            1.0 / (t4 * J[1][2] - t6 * J[1][1] - t8 * J[2][2] + t10 * J[2][1] + t12 * J[2][2] - t14 * J[2][1]);
-        iJ[0][0] = (J[1][1] * J[2][2] - J[1][2] * J[2][1]) * t17;
-        iJ[0][1] = -(J[0][1] * J[2][2] - J[0][2] * J[2][1]) * t17;
-        iJ[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * t17;
-        iJ[1][0] = -(-J[2][0] * J[1][2] + J[1][0] * J[2][2]) * t17;
-        iJ[1][1] = (-t6 + J[0][0] * J[2][2]) * t17;
-        iJ[1][2] = -(-t10 + t14) * t17;
-        iJ[2][0] = (-J[2][0] * J[1][1] + J[1][0] * J[2][1]) * t17;
-        iJ[2][1] = -(-t4 + J[0][0] * J[2][1]) * t17;
-        iJ[2][2] = (-t8 + t12) * t17;
-        const double det = J[0][0] * J[1][1] * J[2][2] - J[0][0] * J[1][2] * J[2][1] - J[1][0] * J[0][1] * J[2][2] +
-                           J[1][0] * J[0][2] * J[2][1] + J[2][0] * J[0][1] * J[1][2] - J[2][0] * J[0][2] * J[1][1];
+        double iJ[3][3], det;
+        inv3_ref(J, iJ, det);
         const double wJ = 1.0 * det;
         if (!(wJ > 0.0)) atomicAdd(a.bad, 1ULL);
         // physical gradient g_i = sum_k iJ[i][k] ghat_k  ->  g_a.g_b = ghat_a^T (iJ^T iJ) ghat_b

@@ -32,6 +32,7 @@ EXPORTS = [
     "femasm_interface_set_buffers", "femasm_interface_apply", "femasm_compress_bc_rows", "femasm_plan_sync", "femasm_last_error",
     "femasm_version", "femasm_plan_set_fast_path", "femasm_plan_get_fast_path", "femasm_assemble_interface", "femasm_error_integrals", "femasm_fill_properties", "femasm_apply_operator",
     "femasm_coo_indices", "femasm_coord_moments", "femasm_rigid_body_modes", "femasm_zero_rows",
+    "femasm_error_integrals_static",
 ]
 
 
@@ -235,6 +236,10 @@ class Plan:
         out = (C.c_double * 2)()
         _check(load().femasm_error_integrals(self._h, _ptr(u), out))
         return out[0], out[1]
+
+    def error_integrals_static(self, u, sums):
+        """The no-allocation variant: u and sums (2 doubles) are device tensors; asynchronous on the plan's stream."""
+        _check(load().femasm_error_integrals_static(self._h, _ptr(u), _ptr(sums)))
 
     def coo_indices(self, coo_i, coo_j):
         """Global (row, column) of every CSR value slot, into two int32 or int64 arrays/tensors of nnz entries."""

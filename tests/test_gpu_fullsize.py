@@ -142,24 +142,48 @@ def test_poisson3d_256_and_elastic2d_2048_properties(env):
     plan.close()
 
 
-def test_bench_two_ranks_end_to_end():
-    """The N > 1 path of bench.py as the driver launches it (torch.distributed.run, one rank per process), rehearsed
-    with two ranks sharing this one GPU over gloo: split interface call, non-blocking exchange, assembly, apply."""
+def _bench_ranks(extra, port, nproc=2, timeout=560):
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
-           "--share-gpu", "--no-cpu-baseline", "--steps", "2", "--warmup", "1", "--nel", "24"]
-    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=280)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(nproc), "--backend",
+           "gloo", "--share-gpu", "--no-cpu-baseline", "--steps", "2", "--warmup", "1"] + extra
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=timeout)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["config"]["global_elements"] == 2 * 24 ** 3
-    assert d["roofline"]["kernel_level"] == 2
+    return json.loads(line)
+
+
+@pytest.mark.parametrize("workload,extra", [("elastic3d", ["--nel", "24"]), ("elastic3d", ["--nel", "32", "--strong"]),
+                                            ("poisson3d", ["--nel", "40", "--strong"]),
+                                            ("elastic3d", ["--nel", "20", "--perturb"])])
+def test_bench_two_ranks_end_to_end_checks_values(workload, extra):
+    """The N > 1 path of bench.py as the driver launches it (torch.distributed.run, one rank per process), rehearsed
+    with two ranks sharing this one GPU over gloo: split interface call, non-blocking exchange, assembly, apply --
+    and, with --check, every rank's rows against a one-plan assembly of the same global mesh."""
+    d = _bench_ranks(["--workload", workload, "--check"] + extra, 29541)
+    nel = int(extra[1])
+    strong = "--strong" in extra
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert d["scaling"] == ("strong" if strong else "weak")
+    assert d["config"]["global_elements"] == (1 if strong else 2) * nel ** 3
+    assert d["roofline"]["kernel_level"] == (0 if "--perturb" in extra else 2)
+    assert d["check"]["rel_K"] <= 1e-13 and d["check"]["rel_b"] <= 1e-13, d["check"]
+
+
+def test_bench_two_ranks_strong_256_elastic_rehearsal():
+    """north_star's scaling mesh (S3 256^3, strong) through the N-rank driver path, two ranks on this one GPU."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150e9:
+        pytest.skip("needs ~110 GB of HBM")
+    d = _bench_ranks(["--workload", "elastic3d", "--nel", "256", "--strong"], 29543)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["global_elements"] == 256 ** 3
+    assert d["roofline"]["kernel_level"] == 2 and d["value"] > 0
 
 
 @pytest.mark.parametrize("kind", ["poisson3d", "elastic3d"])

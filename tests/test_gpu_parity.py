@@ -258,6 +258,66 @@ def test_slabs_plus_interface_exchange_equal_the_global_system(env, kind, dims, 
         plans[r].close()
 
 
+def test_host_material_then_device_material_on_one_plan(env):
+    """A staged copy of a HOST material array must not outlive its call: femasm_assemble_system with host
+    material, then femasm_assemble_interface + femasm_assemble_system with a DIFFERENT device material on the same
+    plan (upper slab of two), against the oracle system of the second material."""
+    torch, F, dev, O, slab = env["torch"], env["F"], env["dev"], env["O"], env["slab"]
+    M, N, P = 7, 6, 9
+    coords = O.perturb_coords(O.uniform_coords(3, M, N, P), 3, M, N, P)
+    rp, ci = O.pattern(3, 3, M, N, P)
+    plane_e = (M - 1) * (N - 1)
+    propsA = O.props_s3(M - 1, N - 1, P - 1, coords, E=90.0, nu=0.28)
+    propsB = O.props_s3(M - 1, N - 1, P - 1, coords, E=33.0, nu=0.17).reshape(-1, 400)
+    propsB[:, 184:400] *= 1.7
+    propsB = propsB.reshape(-1)
+    KB, bB = O.assemble_elastic3d(M, N, P, coords, propsB, rp, ci)
+    O.bc_s3(M, N, P, coords, rp, ci, KB, bB)
+    (ks0, ke0), (ks, ke) = slab.slab_ranges(P, 2)
+    cks, cke = ks - 1, P
+    els, ele = slab.element_range(ks, ke)
+    co = torch.from_numpy(coords.reshape(P, -1)[cks:cke].reshape(-1).copy()).to(dev)
+    plan = F.Plan(F.ELASTIC3D_Q1, M, N, P, coords=co, ks=ks, ke=ke, cks=cks, cke=cke)
+    vals = torch.empty(plan.nnz, dtype=torch.float64, device=dev)
+    b = torch.empty(plan.nrows, dtype=torch.float64, device=dev)
+    (_, sc), _ = plan.interface_buffers()
+    send = torch.empty(sc, dtype=torch.float64, device=dev)
+    plan.interface_set_buffers(send, None)
+    hostA = propsA.reshape(-1, plane_e * 400)[els:ele].reshape(-1).copy()             # HOST array: staged
+    plan.assemble_system(vals, b, material=hostA, stride=400, bc=F.BC_S3_ALLFACES_EXACT, e_ks=els)
+    devB = torch.from_numpy(propsB.reshape(-1, plane_e * 400)[els:ele].reshape(-1).copy()).to(dev)
+    plan.assemble_interface(material=devB, stride=400, bc=F.BC_S3_ALLFACES_EXACT, e_ks=els)
+    plan.assemble_system(vals, b, material=devB, stride=400, bc=F.BC_S3_ALLFACES_EXACT, e_ks=els)
+    # lower slab with material B, fed with the upper slab's send buffer
+    co0 = torch.from_numpy(coords.reshape(P, -1)[0:ke0 + 1].reshape(-1).copy()).to(dev)
+    plan0 = F.Plan(F.ELASTIC3D_Q1, M, N, P, coords=co0, ks=ks0, ke=ke0, cks=0, cke=ke0 + 1)
+    e0, e1 = slab.element_range(ks0, ke0)
+    dev0 = torch.from_numpy(propsB.reshape(-1, plane_e * 400)[e0:e1].reshape(-1).copy()).to(dev)
+    v0 = torch.empty(plan0.nnz, dtype=torch.float64, device=dev)
+    b0 = torch.empty(plan0.nrows, dtype=torch.float64, device=dev)
+    (_, _), (_, rc) = plan0.interface_buffers()
+    assert rc == sc
+    recv = send.clone()                                                               # "RCCL"
+    plan0.interface_set_buffers(None, recv)
+    plan0.assemble_system(v0, b0, material=dev0, stride=400, bc=F.BC_S3_ALLFACES_EXACT, e_ks=e0)
+    plan0.interface_apply(v0, b0, bc=F.BC_S3_ALLFACES_EXACT)
+    K = np.concatenate([v0.cpu().numpy(), vals.cpu().numpy()])
+    bb = np.concatenate([b0.cpu().numpy(), b.cpu().numpy()])
+    assert rel(K, KB) <= TOL and rel(bb, bB) <= TOL
+    plan.close(); plan0.close()
+
+
+def test_compress_bc_rows_rejects_the_poisson_kind(env):
+    """P3 never calls MatZeroRows: its boundary diagonal is the element valence, which the compressed form (diag 1)
+    would misstate."""
+    F = env["F"]
+    case = make_case(env, "p3", (4, 4, 4))
+    plan, vals, _ = gpu_assemble(env, case)
+    with pytest.raises(F.FemasmError):
+        plan.compress_bc_rows(vals, F.BC_POISSON_INLOOP)
+    plan.close()
+
+
 def test_results_are_bitwise_reproducible(env):
     case = make_case(env, "s3", (9, 8, 7))
     p1, v1, b1 = gpu_assemble(env, case)
