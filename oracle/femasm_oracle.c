@@ -791,3 +791,211 @@ void orc_errors_elastic3d(int64_t M, int64_t N, int64_t P, const double *coords,
     *L2 = sqrt(tL2);
     *H1 = sqrt(tH1);
 }
+
+/* ==========================================================================================================
+ * Config 5: SGFEM-enriched Q1 hexahedra.  NO REFERENCE ARITHMETIC EXISTS for this: R3
+ * ("SGFEM_real") holds only bookkeeping -- the macros Q, L1, L2, type, test_dof (R3:39-43), the per-node fields
+ * enrich_type[8] / n_enrich[8] of the element record (R3:46-49, 65-67), their zero fill (R3:1265-1269) and the
+ * dead, non-compiling BlockRedundantDofs / GetNodalRedundantDofs (R3:1467-1595).  The specification below is
+ * owned by this build and shaped by that scaffolding; it is a restatement of the SPEC,
+ * written independently of the HIP kernels (naive B^T D B over the full B matrix, as S3:450-518 does).
+ *
+ *   scalar shape functions of an element:  Phi_{a,0} = N_a,   Phi_{a,1+m} = N_a * phi_m   (m < n_enr),
+ *     phi_m = psi_m - sum_b N_b psi_m(x_b)   (`type` 1, R3:42: SGFEM, enrichment minus its Q1 interpolant)
+ *     phi_m = psi_m                           (`type` 0: GFEM)
+ *     family m is active at local node a iff enrich_type[a] != 0 and m < n_enrich[a]; else Phi_{a,1+m} = 0 here
+ *   node-blocked dofs, D = 3 (1 + n_enr) per node, q = 3 s + c  (ElasticityDOF R3:70-74 repeated per family)
+ *   record = R3's GaussPointCoefficients (R3:52-68; `base` = 408 doubles with 32-bit PetscInt, 416 with 64-bit)
+ *     followed by 64 doubles per family:  psi at the 8 nodes, psi at the 8 Gauss points, grad psi (physical) at the
+ *     8 Gauss points [p][3], psi at the 24 face Gauss points
+ *   Ke, Fe, Ge: the S3 formulas (S3:450-656) with the 8 S scalar functions in place of the 8 N_a
+ *   rows:  all-face Dirichlet as S3 on the displacement dofs (exact value) and 0 on the enriched dofs of boundary
+ *     nodes; every enriched dof whose family is inactive at its node is blocked: unit row, b = 0
+ *     (BlockRedundantDofs R3:1509-1595: MatZeroRows(A, ..., 1.0) on the redundant dofs).  A node takes its flags from
+ *     the element behind it, (max(i-1,0), max(j-1,0), max(k-1,0)), the one element of a node every slab holds.
+ * ========================================================================================================== */
+static int64_t enr_flag(const double *rec, int base, int idx)
+{
+    /* PetscInt enrich_type[8], n_enrich[8] stored inside a struct of PetscScalar, at double 400 (R3:65-67) */
+    if (base == 408) return (int64_t)((const int32_t *)(rec + 400))[idx];
+    return ((const int64_t *)(rec + 400))[idx];
+}
+
+/* gradients [fn][3] and values of the 8 S scalar functions at volume Gauss point p; fn = 8 s + a */
+static void enr_functions_gp(const double coords[24], const double *rec, int base, int n_enr, int sgfem, int p,
+                             double (*g)[3], double *val, double *detJ)
+{
+    double xi[8][3], w[8], N[8], G[3][8], Gx[3][8];
+    orc_gauss_hex8(xi, w);
+    orc_hex_N(xi[p], N);
+    orc_hex_dNdxi(xi[p], G);
+    orc_hex_dNdx(G, coords, Gx, detJ);
+    for (int a = 0; a < 8; a++) {
+        val[a] = N[a];
+        for (int k = 0; k < 3; k++) g[a][k] = Gx[k][a];
+    }
+    for (int m = 0; m < n_enr; m++) {
+        const double *e = rec + base + 64 * m, *psi_n = e, *psi = e + 8, *dpsi = e + 16;
+        double phi = psi[p], dphi[3] = {dpsi[3 * p], dpsi[3 * p + 1], dpsi[3 * p + 2]};
+        if (sgfem) {
+            for (int b = 0; b < 8; b++) {
+                phi = phi - N[b] * psi_n[b];
+                for (int k = 0; k < 3; k++) dphi[k] = dphi[k] - Gx[k][b] * psi_n[b];
+            }
+        }
+        for (int a = 0; a < 8; a++) {
+            int active = enr_flag(rec, base, a) != 0 && m < enr_flag(rec, base, 8 + a);
+            int fn = 8 * (1 + m) + a;
+            val[fn] = active ? N[a] * phi : 0.0;
+            for (int k = 0; k < 3; k++) g[fn][k] = active ? phi * Gx[k][a] + N[a] * dphi[k] : 0.0;
+        }
+    }
+}
+
+void orc_enr_ke(const double coords[24], const double *rec, int base, int n_enr, int sgfem, double *Ke)
+{
+    const int S = 1 + n_enr, D = 3 * S, NR = 8 * D;
+    double g[8 * 8][3], val[8 * 8], J, D6[6][6], factor;
+    double *B = (double *)malloc((size_t)6 * NR * sizeof(double));
+    for (int p = 0; p < 8; p++) {
+        enr_functions_gp(coords, rec, base, n_enr, sgfem, p, g, val, &J);
+        memset(B, 0, (size_t)6 * NR * sizeof(double));
+        for (int a = 0; a < 8; a++)
+            for (int s = 0; s < S; s++) {
+                const double dx = g[8 * s + a][0], dy = g[8 * s + a][1], dz = g[8 * s + a][2];
+                const int c0 = a * D + 3 * s;                /* columns of (a, s, c = 0..2): S3:470-482 */
+                B[0 * NR + c0] = dx; B[1 * NR + c0 + 1] = dy; B[2 * NR + c0 + 2] = dz;
+                B[3 * NR + c0] = dy; B[3 * NR + c0 + 1] = dx;
+                B[4 * NR + c0 + 1] = dz; B[4 * NR + c0 + 2] = dy;
+                B[5 * NR + c0] = dz; B[5 * NR + c0 + 2] = dx;
+            }
+        elastic_D(rec[96 + p], rec[104 + p], D6, &factor);
+        for (int i = 0; i < 6; i++)
+            for (int j = 0; j < 6; j++) D6[i][j] = factor * D6[i][j] * 1.0 * J;
+        for (int i = 0; i < NR; i++)
+            for (int j = 0; j < NR; j++)
+                for (int k = 0; k < 6; k++)
+                    for (int l = 0; l < 6; l++) Ke[NR * i + j] = Ke[NR * i + j] + B[k * NR + i] * D6[k][l] * B[l * NR + j];
+    }
+    free(B);
+}
+
+/* Fe + Ge of the enriched element (S3:520-656 with Phi_{a,s} in place of N_a), added into F[8 D] */
+void orc_enr_fe(const double coords[24], const double *rec, int base, int n_enr, int sgfem, double *F)
+{
+    const int S = 1 + n_enr, D = 3 * S;
+    double g[8 * 8][3], val[8 * 8], J;
+    const double *fx = rec + 160, *fy = rec + 168, *fz = rec + 176;
+    for (int p = 0; p < 8; p++) {
+        enr_functions_gp(coords, rec, base, n_enr, sgfem, p, g, val, &J);
+        double fac = 1.0 * J;
+        for (int a = 0; a < 8; a++)
+            for (int s = 0; s < S; s++) {
+                F[a * D + 3 * s] += fac * val[8 * s + a] * fx[p];
+                F[a * D + 3 * s + 1] += fac * val[8 * s + a] * fy[p];
+                F[a * D + 3 * s + 2] += fac * val[8 * s + a] * fz[p];
+            }
+    }
+    /* natural-BC term over the 24 face points (S3:548-656) */
+    const double *gx = rec + 184, *gy = rec + 256, *gz = rec + 328, *E_B = rec + 112, *nu_B = rec + 136;
+    double xi[24][3], w[24], N[8], D6[6][6], factor, strain[6], z[6], sn[3], Jp;
+    double dx = fabs(coords[0] - coords[9]), dy = fabs(coords[1] - coords[4]), dz = fabs(coords[2] - coords[14]);
+    orc_gauss_hexface24(xi, w);
+    for (int p = 0; p < 24; p++) {
+        orc_hex_N(xi[p], N);
+        elastic_D(E_B[p], nu_B[p], D6, &factor);
+        for (int i = 0; i < 6; i++)
+            for (int j = 0; j < 6; j++) D6[i][j] = factor * D6[i][j];
+        memset(z, 0, sizeof z);
+        strain[0] = gx[3 * p]; strain[1] = gy[3 * p + 1]; strain[2] = gz[3 * p + 2];
+        strain[3] = gx[3 * p + 1] + gy[3 * p];
+        strain[4] = gy[3 * p + 2] + gz[3 * p + 1];
+        strain[5] = gx[3 * p + 2] + gz[3 * p];
+        for (int i = 0; i < 6; i++)
+            for (int j = 0; j < 6; j++) z[i] = z[i] + D6[i][j] * strain[j];
+        int axis = p / 8;
+        double side = ((p / 4) % 2 == 0) ? 1.0 : -1.0;
+        if (axis == 0)      { sn[0] = z[0] * side; sn[1] = z[3] * side; sn[2] = z[5] * side; Jp = (0.5 * dy) * (0.5 * dz); }
+        else if (axis == 1) { sn[0] = z[3] * side; sn[1] = z[1] * side; sn[2] = z[4] * side; Jp = (0.5 * dx) * (0.5 * dz); }
+        else                { sn[0] = z[5] * side; sn[1] = z[4] * side; sn[2] = z[2] * side; Jp = (0.5 * dx) * (0.5 * dy); }
+        double fac = w[p] * Jp;
+        for (int s = 0; s < S; s++) {
+            double phi = 1.0;
+            if (s > 0) {
+                const double *e = rec + base + 64 * (s - 1), *psi_n = e, *psi_b = e + 40;
+                phi = psi_b[p];
+                if (sgfem)
+                    for (int b = 0; b < 8; b++) phi = phi - N[b] * psi_n[b];
+            }
+            for (int a = 0; a < 8; a++) {
+                int active = (s == 0) || (enr_flag(rec, base, a) != 0 && (s - 1) < enr_flag(rec, base, 8 + a));
+                double v = active ? N[a] * phi : 0.0;
+                for (int c = 0; c < 3; c++) F[a * D + 3 * s + c] += fac * v * sn[c];
+            }
+        }
+    }
+}
+
+int orc_assemble_enriched3d(int64_t M, int64_t N, int64_t P, const double *coords, const double *props, int stride,
+                            int base, int n_enr, int sgfem, const int64_t *rowptr, const int32_t *colidx,
+                            double *vals, double *b, int64_t e0, int64_t e1)
+{
+    const int D = 3 * (1 + n_enr), NR = 8 * D;
+    double el[24];
+    double *Ae = (double *)malloc((size_t)NR * NR * sizeof(double)), *Fe = (double *)malloc((size_t)NR * sizeof(double));
+    int64_t *eq = (int64_t *)malloc((size_t)NR * sizeof(int64_t));
+    int rc = 0;
+    (void)P;
+    for (int64_t ek = e0; ek < e1 && !rc; ek++)
+        for (int64_t ej = 0; ej < N - 1 && !rc; ej++)
+            for (int64_t ei = 0; ei < M - 1 && !rc; ei++) {
+                const double *q = props + (int64_t)stride * (ei + (M - 1) * (ej + (N - 1) * ek));
+                hex_coords(coords, M, N, ei, ej, ek, el);
+                for (int n = 0; n < 8; n++)
+                    for (int c = 0; c < D; c++)
+                        eq[D * n + c] = D * ((ei + HEX_DI[n]) + M * ((ej + HEX_DJ[n]) + N * (ek + HEX_DK[n]))) + c;
+                if (vals) {
+                    memset(Ae, 0, (size_t)NR * NR * sizeof(double));
+                    orc_enr_ke(el, q, base, n_enr, sgfem, Ae);
+                    for (int r = 0; r < NR && !rc; r++)
+                        for (int c = 0; c < NR; c++)
+                            if (csr_add(rowptr, colidx, vals, eq[r], eq[c], Ae[NR * r + c])) { rc = -1; break; }
+                }
+                if (b) {
+                    memset(Fe, 0, (size_t)NR * sizeof(double));
+                    orc_enr_fe(el, q, base, n_enr, sgfem, Fe);
+                    for (int t = 0; t < NR; t++) b[eq[t]] = b[eq[t]] + Fe[t];
+                }
+            }
+    free(Ae); free(Fe); free(eq);
+    return rc;
+}
+
+/* rows: S3's all-face Dirichlet (if dirichlet != 0) and the blocked redundant dofs (always) */
+void orc_bc_enriched3d(int64_t M, int64_t N, int64_t P, const double *coords, const double *props, int stride,
+                       int base, int n_enr, int dirichlet, const int64_t *rowptr, const int32_t *colidx,
+                       double *vals, double *b)
+{
+    const int D = 3 * (1 + n_enr);
+    for (int64_t k = 0; k < P; k++)
+        for (int64_t j = 0; j < N; j++)
+            for (int64_t i = 0; i < M; i++) {
+                const int64_t node = i + M * (j + N * k);
+                const int bnd = (i == 0 || i == M - 1 || j == 0 || j == N - 1 || k == 0 || k == P - 1);
+                /* the element behind the node and the node's place in it */
+                const int64_t ei = i > 0 ? i - 1 : 0, ej = j > 0 ? j - 1 : 0, ek = k > 0 ? k - 1 : 0;
+                int a = -1;
+                for (int n = 0; n < 8; n++)
+                    if (HEX_DI[n] == (i > 0) && HEX_DJ[n] == (j > 0) && HEX_DK[n] == (k > 0)) a = n;
+                const double *q = props + (int64_t)stride * (ei + (M - 1) * (ej + (N - 1) * ek));
+                double vel[3];
+                orc_elastic_exact(coords + 3 * node, vel, NULL, NULL, 0, 0);
+                for (int d = 0; d < D; d++) {
+                    const int m = d / 3 - 1;
+                    const int blocked = (d >= 3) && !(enr_flag(q, base, a) != 0 && m < enr_flag(q, base, 8 + a));
+                    if (!(blocked || (dirichlet && bnd))) continue;
+                    if (b) b[D * node + d] = (d < 3 && dirichlet && bnd) ? vel[d] : 0.0;
+                    if (vals) zero_row_unit_diag(rowptr, colidx, vals, D * node + d);
+                }
+            }
+}

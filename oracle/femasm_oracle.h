@@ -123,6 +123,18 @@ void orc_errors_poisson3d(int64_t M, int64_t N, int64_t P, const double *coords,
 void orc_errors_elastic3d(int64_t M, int64_t N, int64_t P, const double *coords,
                           const double *x, double *h, double *L2, double *H1); /* S3:1041-1151 */
 
+/* ---- config 5: SGFEM-enriched hexahedra.  NO REFERENCE ARITHMETIC EXISTS; this restates
+ * the build's own specification (femasm_oracle.c has the short form), shaped by R3:39-49,
+ * 52-68, 1265-1269, 1467-1595.  base = 408 | 416 (width of PetscInt), record stride = base + 64 n_enr. */
+void orc_enr_ke(const double coords[24], const double *rec, int base, int n_enr, int sgfem, double *Ke);
+void orc_enr_fe(const double coords[24], const double *rec, int base, int n_enr, int sgfem, double *F);
+int  orc_assemble_enriched3d(int64_t M, int64_t N, int64_t P, const double *coords, const double *props, int stride,
+                             int base, int n_enr, int sgfem, const int64_t *rowptr, const int32_t *colidx,
+                             double *vals, double *b, int64_t e0, int64_t e1);
+void orc_bc_enriched3d(int64_t M, int64_t N, int64_t P, const double *coords, const double *props, int stride,
+                       int base, int n_enr, int dirichlet, const int64_t *rowptr, const int32_t *colidx,
+                       double *vals, double *b);
+
 #ifdef __cplusplus
 }
 #endif

@@ -195,3 +195,84 @@ def fe_poisson(coords):
     out = np.zeros(8)
     lib().orc_fe_poisson_hex(_dp(np.ascontiguousarray(coords, dtype=np.float64)), _dp(out))
     return out
+
+
+# --------------------------------------------------------------------------
+# config 5 (SGFEM-enriched hexahedra): the build's own specification, no reference arithmetic exists
+# --------------------------------------------------------------------------
+def enr_stride(n_enr, base=408):
+    return base + 64 * n_enr
+
+
+def enr_ke(coords, rec, n_enr, sgfem=1, base=408):
+    D = 3 * (1 + n_enr)
+    out = np.zeros((8 * D) ** 2)
+    lib().orc_enr_ke(_dp(np.ascontiguousarray(coords, dtype=np.float64)), _dp(rec), C.c_int(base), C.c_int(n_enr),
+                     C.c_int(sgfem), _dp(out))
+    return out.reshape(8 * D, 8 * D)
+
+
+def enr_fe(coords, rec, n_enr, sgfem=1, base=408):
+    D = 3 * (1 + n_enr)
+    out = np.zeros(8 * D)
+    lib().orc_enr_fe(_dp(np.ascontiguousarray(coords, dtype=np.float64)), _dp(rec), C.c_int(base), C.c_int(n_enr),
+                     C.c_int(sgfem), _dp(out))
+    return out
+
+
+def assemble_enriched3d(M, N, P, coords, props, rowptr, colidx, n_enr, sgfem=1, base=408, e0=0, e1=None,
+                        want_K=True, want_b=True):
+    e1 = P - 1 if e1 is None else e1
+    D = 3 * (1 + n_enr)
+    vals = np.zeros(len(colidx), dtype=np.float64) if want_K else None
+    b = np.zeros(D * M * N * P, dtype=np.float64) if want_b else None
+    rc = lib().orc_assemble_enriched3d(C.c_int64(M), C.c_int64(N), C.c_int64(P), _dp(coords), _dp(props),
+                                       C.c_int(enr_stride(n_enr, base)), C.c_int(base), C.c_int(n_enr),
+                                       C.c_int(sgfem), _i64p(rowptr), _i32p(colidx), _dp(vals), _dp(b),
+                                       C.c_int64(e0), C.c_int64(e1))
+    assert rc == 0
+    return vals, b
+
+
+def bc_enriched3d(M, N, P, coords, props, rowptr, colidx, vals, b, n_enr, dirichlet=True, base=408):
+    lib().orc_bc_enriched3d(C.c_int64(M), C.c_int64(N), C.c_int64(P), _dp(coords), _dp(props),
+                            C.c_int(enr_stride(n_enr, base)), C.c_int(base), C.c_int(n_enr),
+                            C.c_int(1 if dirichlet else 0), _i64p(rowptr), _i32p(colidx), _dp(vals), _dp(b))
+
+
+def props_enriched(mx, my, mz, coords, n_enr, psi_funcs, etype=None, nenrich=None, base=408, E=90.0, nu=0.28):
+    """R3 records (S3 fill + enrich flags) followed by the enrichment block of each family.
+    psi_funcs: list of n_enr callables (x, y, z arrays) -> (psi, dpsi/dx, dpsi/dy, dpsi/dz).
+    etype / nenrich: int arrays [P, N, M] per NODE (defaults: every node enriched with all families); every element
+    record gets its 8 nodes' flags, so the records of the elements around a node agree."""
+    stride = enr_stride(n_enr, base)
+    s3 = props_s3(mx, my, mz, coords, E=E, nu=nu, stride=400).reshape(-1, 400)
+    nel = mx * my * mz
+    out = np.zeros((nel, stride))
+    out[:, :400] = s3
+    M, N, P = mx + 1, my + 1, mz + 1
+    if etype is None:
+        etype = np.ones((P, N, M), dtype=np.int64)
+    if nenrich is None:
+        nenrich = np.full((P, N, M), n_enr, dtype=np.int64)
+    c4 = coords.reshape(P, N, M, 3)
+    HD = [(0, 0, 0), (0, 1, 0), (1, 1, 0), (1, 0, 0), (0, 0, 1), (0, 1, 1), (1, 1, 1), (1, 0, 1)]
+    flags = np.zeros((nel, 16), dtype=np.int32 if base == 408 else np.int64)
+    xn = []
+    for a, (di, dj, dk) in enumerate(HD):
+        sl = (slice(dk, dk + mz), slice(dj, dj + my), slice(di, di + mx))
+        flags[:, a] = etype[sl].reshape(-1)
+        flags[:, 8 + a] = nenrich[sl].reshape(-1)
+        xn.append(c4[sl].reshape(-1, 3))
+    out[:, 400:base] = flags.view(np.float64).reshape(nel, base - 400)
+    gp = s3[:, 0:24].reshape(nel, 8, 3)
+    gpb = s3[:, 24:96].reshape(nel, 24, 3)
+    for m, f in enumerate(psi_funcs):
+        o = base + 64 * m
+        for a in range(8):
+            out[:, o + a] = f(xn[a][:, 0], xn[a][:, 1], xn[a][:, 2])[0]
+        v = f(gp[:, :, 0], gp[:, :, 1], gp[:, :, 2])
+        out[:, o + 8:o + 16] = v[0]
+        out[:, o + 16:o + 40] = np.stack([v[1], v[2], v[3]], axis=-1).reshape(nel, 24)
+        out[:, o + 40:o + 64] = f(gpb[:, :, 0], gpb[:, :, 1], gpb[:, :, 2])[0]
+    return out.reshape(-1)

@@ -8,7 +8,7 @@ system at 1e-13.
   config 2  FEM_elsatic2D 2048^2: tests/test_gpu_fullsize.py (uniform mesh, golden diagonal)
   config 3  FEM_poisson3D 256^3 over 8 slabs by the DMDA rule (257 layers -> 33, 32 x 7)
   config 4  SGFEM_elastic3D 128^3, 1 plan and 8 slabs (129 -> 17, 16 x 7), uniform mesh = what bench.py times
-  config 4' 256^3 (north_star's scaling size) on one GPU: window in the far corner (value offsets beyond 2^32)
+  config 4' 256^3 (north_star's scaling size) on one GPU: window in the far corner (value offsets beyond 2^31)
 """
 import numpy as np
 import pytest
@@ -235,7 +235,7 @@ def test_config4_elastic3d_128_over_8_slabs(env):
 
 
 def test_north_star_256_elastic_on_one_gpu_far_corner_window(env):
-    """S3 256^3 (50.9 M rows, 4.09e9 values = 32.7 GB: value offsets beyond 2^32) on the uniform mesh: no slot
+    """S3 256^3 (50.9 M rows, 4.09e9 values = 32.7 GB: value offsets beyond 2^31) on the uniform mesh: no slot
     unwritten, a window in the far corner against the oracle."""
     torch, F, synth, slab, dev = env["torch"], env["F"], env["synth"], env["slab"], env["dev"]
     free, _ = torch.cuda.mem_get_info()
@@ -256,7 +256,7 @@ def test_north_star_256_elastic_on_one_gpu_far_corner_window(env):
     step = 1 << 29                                  # the NaN scan in pieces: a 4 GB mask at once is not needed
     for o in range(0, plan.nnz, step):
         assert not torch.isnan(vals[o:o + step]).any()
-    assert _node_start(slab, 3, M, M, M, M - 2, M - 2, M - 2) > 2 ** 32
+    assert _node_start(slab, 3, M, M, M, M - 2, M - 2, M - 2) > 2 ** 31    # value offsets overflow int32
     rK, rb = _window_check(env, "s3", vals, b, coords, props, M, (M - 7, M - 7, M - 7))
     assert rK <= TOL and rb <= TOL, (rK, rb)
     plan.close()
