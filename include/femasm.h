@@ -25,7 +25,10 @@ extern "C" {
 enum {
   FEMASM_POISSON3D_Q1      = 0, /* P3: 8-node hex, dof 1, 8 Gauss points                */
   FEMASM_PLANE_STRAIN2D_Q1 = 1, /* E2: 4-node quad, dof 2, 4 Gauss points               */
-  FEMASM_ELASTIC3D_Q1      = 2  /* S3/R3 (all enrich_type == 0): 8-node hex, dof 3      */
+  FEMASM_ELASTIC3D_Q1      = 2, /* S3/R3 (all enrich_type == 0): 8-node hex, dof 3      */
+  FEMASM_ELASTIC3D_ENRICHED = 3 /* BASELINE config 5: SGFEM-enriched hex, dof 3(1+n_enr): no reference arithmetic
+                                   exists (R3 holds the scaffolding only, R3:39-68, 1265-1269, 1467-1595); the
+                                   specification is this engine's, DESIGN.md section 9                  */
 };
 
 enum {
@@ -40,7 +43,8 @@ enum {
  * BOX stencil, width 1, non-periodic, natural node order n = i + M*(j + N*k). */
 typedef struct {
   int32_t problem;      /* FEMASM_* problem kind                                              */
-  int32_t reserved;
+  int32_t n_enr;        /* FEMASM_ELASTIC3D_ENRICHED: enrichment families per node, 0..3 (the DMDA's dof
+                           is 3(1+n_enr); R3:43 test_dof); 0 for the other kinds                      */
   int64_t M, N, P;      /* global node counts per direction (P = 1 in 2-D)                    */
   int64_t ks, ke;       /* owned node layers [ks,ke) of the slowest direction (z in 3-D, y in
                            2-D): DMDA slab split.  0,P (0,N in 2-D) on one GPU.               */
@@ -59,6 +63,11 @@ typedef struct {
   int64_t e_ks;         /* first element layer held in gp[] (owned elements start here)       */
   const double *gp;     /* element index ei + mx*(ej + my*(ek - e_ks))                        */
   double E, nu;         /* FEMASM_MAT_UNIFORM                                                 */
+  int32_t enr_mode;     /* FEMASM_ELASTIC3D_ENRICHED: 0 = SGFEM, phi = psi - I_h psi (`type` 1, R3:42);
+                           1 = GFEM, phi = psi (`type` 0).  Record stride = 408 | 416 (R3:52-68 with 32- /
+                           64-bit PetscInt) + 64 n_enr: per family psi at the 8 nodes, at the 8 Gauss points,
+                           grad psi at the 8 Gauss points [p][3], psi at the 24 face Gauss points    */
+  int32_t reserved;
 } femasm_material;
 
 /* "quad": rule 0 = the reference's 2-point Gauss rule with the literal abscissa
@@ -117,6 +126,11 @@ int femasm_plan_set_stream(femasm_plan *plan, void *stream);
  * levels differ by rounding only. */
 int femasm_plan_set_fast_path(femasm_plan *plan, int level);
 int femasm_plan_get_fast_path(femasm_plan *plan, int *level);
+/* No counterpart in the reference.  FEMASM_ELASTIC3D_ENRICHED: how the local B^T D B contraction of the enriched
+ * blocks is done: 0 = FP64 VALU, 1 = v_mfma_f64_16x16x4 (n_enr = 1: the 16 scalar shape functions of an element are
+ * one MFMA tile), -1 = the default (the faster one as measured on MI355X).  Results differ by
+ * rounding only. */
+int femasm_plan_set_enriched_contraction(femasm_plan *plan, int mode);
 
 /* Sparsity pattern of the owned rows (A12): rowptr is local (starts at 0, int64 so
  * 256^3 elastic fits), colidx holds GLOBAL column ids (= PETSc natural numbering for

@@ -7,6 +7,7 @@
 #include "../../include/femasm.h"
 #include "femasm_kernels.h"
 #include "femasm_sweep.h"
+#include "femasm_enriched.h"
 
 #include <hipcub/hipcub.hpp>
 
@@ -138,12 +139,20 @@ struct femasm_plan {
   double *stage_u = nullptr;           // femasm_error_integrals: device copy of a host solution vector
   int64_t stage_u_count = 0;
   double *static_scratch = nullptr;    // this device's copy of the file-scope `scratch` array (femasm_error_integrals_static)
+
+  // config 5 (KIND_ENRICHED)
+  int n_enr = 0;                       // enrichment families per node: dof = 3 (1 + n_enr)
+  int enr_mfma = -1;                   // contraction of k_enr_elem: 0 VALU, 1 FP64 MFMA (n_enr == 1 only), -1 default
+  double *ke_ring = nullptr;           // element-matrix ring: ke_nring element layers
+  int64_t ke_ring_count = 0;
+  int ke_nring = 0;
 };
 
 namespace {
 
-int traits_of(int kind, int &nsd, int &dof, int &nen, int &ngp, int &nfe) {
+int traits_of(int kind, int &nsd, int &dof, int &nen, int &ngp, int &nfe, int n_enr = 0) {
   switch (kind) {
+    case KIND_ENRICHED: nsd = 3; dof = 3 * (1 + n_enr); nen = 8; ngp = 8; nfe = 8 * dof; return 0;
     case KIND_POISSON: nsd = 3; dof = 1; nen = 8; ngp = 8; nfe = 8; return 0;
     case KIND_PLANE:   nsd = 2; dof = 2; nen = 4; ngp = 4; nfe = 8; return 0;
     case KIND_ELASTIC: nsd = 3; dof = 3; nen = 8; ngp = 8; nfe = 48; return 0;
@@ -445,6 +454,173 @@ int launch_rhs(femasm_plan *p, const femasm_material *mat, int bc, double *out, 
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Config 5: assembly of the enriched kind.  Element layers are processed in chunks through a ring of element
+// matrices (k_enr_elem), each chunk followed by the segmented reduction of the node layers it completes
+// (k_enr_gather); then the right-hand side.
+// ---------------------------------------------------------------------------------------------------------
+template <int S>
+void launch_enr_elem(femasm_plan *p, const EnrArgs &a, int64_t nelem, bool mfma) {
+  constexpr int NW = EnrCfg<S>::NW;
+  const dim3 grid((unsigned)((nelem + NW - 1) / NW));
+  if constexpr (S == 2) {
+    if (mfma) {
+      hipLaunchKernelGGL((k_enr_elem<2, true>), grid, dim3(64 * NW), 0, p->stream, p->s, a);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((k_enr_elem<S, false>), grid, dim3(64 * NW), 0, p->stream, p->s, a);
+}
+
+int assemble_enriched(femasm_plan *p, const femasm_material *mat, int bc, double *csr_values, double *b,
+                      femasm_stats *stats) {
+  const auto t_begin = std::chrono::steady_clock::now();
+  const Slab &s = p->s;
+  const int S = 1 + p->n_enr, D = 3 * S;
+  if (bc != FEMASM_BC_NONE && bc != FEMASM_BC_S3_ALLFACES_EXACT)
+    return fail(FEMASM_ERR_ARG, "the enriched kind takes FEMASM_BC_NONE or FEMASM_BC_S3_ALLFACES_EXACT");
+  if (!mat || mat->layout != FEMASM_MAT_AOS || !mat->gp)
+    return fail(FEMASM_ERR_ARG, "the enriched kind needs the AoS records (R3 GaussPointCoefficients + enrichment blocks)");
+  const int base = mat->stride - 64 * p->n_enr;
+  if (base != 408 && base != 416 && !(p->n_enr == 0 && mat->stride == 400))
+    return fail(FEMASM_ERR_ARG, "enriched record stride %d is not 408 + 64 n_enr (32-bit PetscInt) or 416 + 64 n_enr", mat->stride);
+  if (mat->e_ks > s.els) return fail(FEMASM_ERR_ARG, "material starts above the first assembled element layer");
+  if (!is_device_ptr(mat->gp) || (csr_values && !is_device_ptr(csr_values)) || (b && !is_device_ptr(b)))
+    return fail(FEMASM_ERR_ARG, "the enriched kind works on device-resident records, csr_values and b");
+  if (mat->enr_mode != 0 && mat->enr_mode != 1) return fail(FEMASM_ERR_ARG, "enr_mode %d: 0 = SGFEM, 1 = GFEM", mat->enr_mode);
+  p->s.mat_e_ks = mat->e_ks;
+  p->gp_cur = mat->gp;
+  const int64_t M = s.dim[0], N = s.dim[1], P = s.dim[2];
+  const int64_t eplane = (M - 1) * (N - 1), nlay = s.ele - s.els;
+  const int64_t KE = 64 * (int64_t)D * D;
+
+  EnrArgs a{};
+  a.coords = p->coords;
+  a.gp = mat->gp;
+  a.bad = p->bad;
+  a.cke = p->cke;
+  a.stride = mat->stride;
+  a.base = (p->n_enr == 0 && mat->stride == 400) ? 400 : base;  // (n_enr == 0 never reads the flags)
+  a.sgfem = mat->enr_mode == 0 ? 1 : 0;
+  a.bc = bc;
+  a.elemF = p->elemF;
+  HIPCHK(hipMemsetAsync(p->bad, 0, 4 * sizeof(unsigned long long), p->stream));
+  if (stats) HIPCHK(hipEventRecord(p->ev[0], p->stream));
+
+  if (csr_values && nlay > 0) {
+    // ring of element layers: as many as the scratch budget holds (FEMASM_ENR_SCRATCH_MB, default 3072), at least 2
+    int64_t budget = 3072;
+    if (const char *e = getenv("FEMASM_ENR_SCRATCH_MB")) budget = atoll(e) > 0 ? atoll(e) : budget;
+    const int64_t layer_doubles = eplane * KE;
+    int64_t nring = (budget << 20) / (layer_doubles * 8);
+    if (nring > nlay + 1) nring = nlay + 1;
+    if (nring < 2) nring = 2;
+    if (nring * layer_doubles > p->ke_ring_count) {
+      if (p->ke_ring) (void)hipFree(p->ke_ring);
+      p->ke_ring = nullptr;
+      p->ke_ring_count = 0;
+      HIPCHK(hipMalloc(&p->ke_ring, (size_t)(nring * layer_doubles) * sizeof(double)));
+      p->ke_ring_count = nring * layer_doubles;
+    }
+    p->ke_nring = (int)nring;
+    a.ke = p->ke_ring;
+    a.nring = (int)nring;
+    const int64_t chunk = nring - 1;
+    const bool mfma = (S == 2) && (p->enr_mfma < 0 ? true : p->enr_mfma != 0);
+    auto gather = [&](double *out, int64_t l0, int64_t l1, int iface) {
+      if (l1 <= l0) return;
+      EnrArgs g = a;
+      g.out = out;
+      g.s0 = l0;
+      g.s1 = l1;
+      g.iface = iface;
+      g.base_off = iface ? row_start(s, 0, 0, l0, 0) : 0;  // owned rows: positions relative to the slab's first row
+      const int64_t nn = M * N * (l1 - l0);
+      const dim3 grid((unsigned)((nn + ENR_GW - 1) / ENR_GW));
+      if (D <= 3) hipLaunchKernelGGL(k_enr_gather<3>, grid, dim3(64 * ENR_GW), 0, p->stream, s, g);
+      else if (D <= 6) hipLaunchKernelGGL(k_enr_gather<6>, grid, dim3(64 * ENR_GW), 0, p->stream, s, g);
+      else if (D <= 9) hipLaunchKernelGGL(k_enr_gather<9>, grid, dim3(64 * ENR_GW), 0, p->stream, s, g);
+      else hipLaunchKernelGGL(k_enr_gather<12>, grid, dim3(64 * ENR_GW), 0, p->stream, s, g);
+    };
+    if (M * N * (s.ke - s.ks + 1) / ENR_GW >= ((int64_t)1 << 31)) return fail(FEMASM_ERR_ARG, "slab too large for one launch");
+    if (stats) HIPCHK(hipEventRecord(p->ev[4], p->stream));
+    for (int64_t L0 = s.els; L0 < s.ele; L0 += chunk) {
+      const int64_t L1 = (L0 + chunk < s.ele) ? L0 + chunk : s.ele;
+      EnrArgs el = a;
+      el.L0 = L0;
+      el.L1 = L1;
+      const int64_t nelem = eplane * (L1 - L0);
+      switch (S) {
+        case 1: launch_enr_elem<1>(p, el, nelem, false); break;
+        case 2: launch_enr_elem<2>(p, el, nelem, mfma); break;
+        case 3: launch_enr_elem<3>(p, el, nelem, false); break;
+        default: launch_enr_elem<4>(p, el, nelem, false); break;
+      }
+      HIPCHK(hipGetLastError());
+      if (L0 == s.els && s.ks > 0 && p->send)  // partial rows of node layer ks-1 (element layer els only), owed to the rank below
+        gather(p->send, s.ks - 1, s.ks, 1);
+      // node layers this chunk completes: k needs element layers k-1 and k (those this rank assembles)
+      const int64_t n0 = (L0 == s.els) ? s.ks : L0, n1 = (L1 == s.ele) ? s.ke : L1;
+      gather(csr_values, n0, n1, 0);
+      HIPCHK(hipGetLastError());
+    }
+    if (stats) HIPCHK(hipEventRecord(p->ev[5], p->stream));
+  }
+  if (stats) HIPCHK(hipEventRecord(p->ev[1], p->stream));
+  if (b) {
+    if (p->nel > 0) {
+      const dim3 grid((unsigned)((p->nel + 127) / 128));
+      switch (S) {
+        case 1: hipLaunchKernelGGL(k_enr_rhs_elem<1>, grid, dim3(128), 0, p->stream, s, a, p->nel); break;
+        case 2: hipLaunchKernelGGL(k_enr_rhs_elem<2>, grid, dim3(128), 0, p->stream, s, a, p->nel); break;
+        case 3: hipLaunchKernelGGL(k_enr_rhs_elem<3>, grid, dim3(128), 0, p->stream, s, a, p->nel); break;
+        default: hipLaunchKernelGGL(k_enr_rhs_elem<4>, grid, dim3(128), 0, p->stream, s, a, p->nel); break;
+      }
+    }
+    auto rgather = [&](double *out, int64_t l0, int64_t l1, int iface) {
+      if (l1 <= l0) return;
+      EnrArgs g = a;
+      g.out = out;
+      g.s0 = l0;
+      g.s1 = l1;
+      g.iface = iface;
+      const int64_t nt = M * N * (l1 - l0) * D;
+      hipLaunchKernelGGL(k_enr_rhs_gather, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, p->stream, s, g);
+    };
+    rgather(b, s.ks, s.ke, 0);
+    if (s.ks > 0 && p->send) rgather(p->send + p->send_nnz, s.ks - 1, s.ks, 1);
+    HIPCHK(hipGetLastError());
+  }
+  if (stats) HIPCHK(hipEventRecord(p->ev[2], p->stream));
+  unsigned long long *flags = p->flags_host;
+  flags[0] = 0;
+  HIPCHK(hipMemcpyAsync(flags, p->bad, sizeof(unsigned long long), hipMemcpyDeviceToHost, p->stream));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  if (stats) {
+    float k_ms = 0, r_ms = 0, m_ms = 0;
+    HIPCHK(hipEventElapsedTime(&k_ms, p->ev[0], p->ev[1]));
+    HIPCHK(hipEventElapsedTime(&r_ms, p->ev[1], p->ev[2]));
+    if (csr_values && nlay > 0) HIPCHK(hipEventElapsedTime(&m_ms, p->ev[4], p->ev[5]));
+    stats->ms_kernel_K = k_ms;
+    stats->ms_kernel_rhs = r_ms;
+    stats->ms_kernel_main = m_ms;
+    stats->ms_staging = 0.0;
+    stats->nel = p->nel;
+    stats->nrows = p->nrows;
+    stats->nnz = p->nnz;
+    stats->bad_detJ = (int64_t)flags[0];
+    // algorithmic bytes (SURVEY 8(d) with dof = D): values out, coordinates, E and nu per Gauss point, and per family
+    // the 40 doubles of enrichment data the stiffness reads (b: + f, the natural-BC inputs and 24 more per family)
+    stats->bytes_K = 8.0 * p->nnz + 8.0 * 3 * p->nnodes + (16.0 * 8 + 8.0 * 40 * p->n_enr) * p->nel;
+    stats->bytes_system = stats->bytes_K + 8.0 * p->nrows + (8.0 * 3 * 8 + 8.0 * 264 + 8.0 * 24 * p->n_enr) * p->nel;
+    stats->bytes_main = stats->bytes_K;
+    stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  }
+  (void)P;
+  if (flags[0]) return fail(FEMASM_ERR_GEOMETRY, "%llu Gauss points with non-positive or NaN det(J)", flags[0]);
+  return FEMASM_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -456,7 +632,10 @@ int femasm_plan_create(const femasm_mesh *mesh, const femasm_quad *quad, int dev
   if (!mesh || !out) return fail(FEMASM_ERR_ARG, "femasm_plan_create: null argument");
   *out = nullptr;
   int nsd, dof, nen, ngp, nfe;
-  if (traits_of(mesh->problem, nsd, dof, nen, ngp, nfe))
+  const int n_enr = (mesh->problem == KIND_ENRICHED) ? mesh->n_enr : 0;
+  if (n_enr < 0 || n_enr > ENR_MAX_S - 1)
+    return fail(FEMASM_ERR_ARG, "n_enr %d not in 0..%d (enrichment families per node)", n_enr, ENR_MAX_S - 1);
+  if (traits_of(mesh->problem, nsd, dof, nen, ngp, nfe, n_enr))
     return fail(FEMASM_ERR_ARG, "unknown problem kind %d", mesh->problem);
   if (quad && (quad->rule != 0 || (quad->ngp != 0 && quad->ngp != ngp)))
     return fail(FEMASM_ERR_ARG, "only the reference 2-point Gauss rule (rule 0, ngp %d) is supported", ngp);
@@ -484,6 +663,7 @@ int femasm_plan_create(const femasm_mesh *mesh, const femasm_quad *quad, int dev
   if (!p) return fail(FEMASM_ERR_NOMEM, "out of host memory");
   p->device = device;
   p->kind = mesh->problem;
+  p->n_enr = n_enr;
   if (int rcs = static_scratch_for(device, &p->static_scratch)) {  // set-up of the no-allocation entry point, once per device
     delete p;
     return rcs;
@@ -549,6 +729,7 @@ int femasm_plan_create(const femasm_mesh *mesh, const femasm_quad *quad, int dev
   // element vectors: blocks of 16 elements x nen*dof lines (ef_idx in femasm_kernels.h)
   p->nelp = ((p->nel > 0 ? p->nel : 1) + 15) & ~(int64_t)15;
   p->elemF_count = p->nelp * nen * dof;
+  if (p->kind == KIND_ENRICHED) p->elemF_count = p->nelp * nen * dof;
   if (p->kind == KIND_ELASTIC) {  // or the records of the runs kernel (femasm_kernels.h), whichever is larger
     const int64_t nlay = p->s.ele - p->s.els;
     const int64_t recs = ((nlay + RUNS_ZC - 1) / RUNS_ZC) * (N - 1) * ((M - 1 + 15) / 16) * (RUNS_ZC + 1) * 128;
@@ -592,7 +773,7 @@ int femasm_plan_destroy(femasm_plan *p) {
   }
 #endif
   void *bufs[] = {p->coords_dev, p->rowptr, p->colidx, p->elemF, p->own_send ? p->send : nullptr,
-                  p->own_recv ? p->recv : nullptr, p->bad, p->stage_vals, p->stage_b, p->stage_gp, p->lines, p->partial, p->stage_u};
+                  p->own_recv ? p->recv : nullptr, p->bad, p->stage_vals, p->stage_b, p->stage_gp, p->lines, p->partial, p->stage_u, p->ke_ring};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   if (p->flags_host) (void)hipHostFree(p->flags_host);
@@ -640,7 +821,7 @@ int femasm_scatter_map(femasm_plan *p, int64_t *map_out) {
   if (!p || !map_out) return fail(FEMASM_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(p->device));
   int nsd, dof, nen, ngp, nfe;
-  traits_of(p->kind, nsd, dof, nen, ngp, nfe);
+  traits_of(p->kind, nsd, dof, nen, ngp, nfe, p->n_enr);
   const int nr = nen * dof;
   const int64_t total = p->nel * nr * nr;
   if (total == 0) return FEMASM_OK;
@@ -666,10 +847,11 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
   const int bc = bcs ? bcs->kind : FEMASM_BC_NONE;
   const Slab &s = p->s;
   int nsd, dof, nen, ngp, nfe;
-  traits_of(p->kind, nsd, dof, nen, ngp, nfe);
+  traits_of(p->kind, nsd, dof, nen, ngp, nfe, p->n_enr);
 
   // argument checks, before anything is launched
   if (bc < 0 || bc > 3) return fail(FEMASM_ERR_ARG, "unknown bc kind %d", bc);
+  if (p->kind == KIND_ENRICHED) return assemble_enriched(p, mat, bc, csr_values, b, stats);
   if ((bc == FEMASM_BC_POISSON_INLOOP && p->kind != KIND_POISSON) ||
       (bc == FEMASM_BC_E2_COMPRESSION && p->kind != KIND_PLANE) ||
       (bc == FEMASM_BC_S3_ALLFACES_EXACT && p->kind != KIND_ELASTIC))
@@ -856,6 +1038,16 @@ int femasm_plan_set_fast_path(femasm_plan *p, int level) {
   return FEMASM_OK;
 }
 
+int femasm_plan_set_enriched_contraction(femasm_plan *p, int mode) {
+  if (!p) return fail(FEMASM_ERR_ARG, "null plan");
+  if (p->kind != KIND_ENRICHED) return fail(FEMASM_ERR_ARG, "not an enriched plan");
+  if (mode < -1 || mode > 1) return fail(FEMASM_ERR_ARG, "mode %d: -1 default, 0 VALU, 1 FP64 MFMA", mode);
+  if (mode == 1 && p->n_enr != 1)
+    return fail(FEMASM_ERR_ARG, "the FP64 MFMA contraction exists for n_enr = 1 (16 scalar functions = one 16x16x4 tile)");
+  p->enr_mfma = mode;
+  return FEMASM_OK;
+}
+
 int femasm_plan_get_fast_path(femasm_plan *p, int *level) {
   if (!p || !level) return fail(FEMASM_ERR_ARG, "null argument");
   *level = p->fast_level;
@@ -864,6 +1056,8 @@ int femasm_plan_get_fast_path(femasm_plan *p, int *level) {
 
 int femasm_assemble_interface(femasm_plan *p, const femasm_material *mat, const femasm_bc *bcs) {
   if (!p) return fail(FEMASM_ERR_ARG, "null plan");
+  if (p->kind == KIND_ENRICHED)
+    return fail(FEMASM_ERR_ARG, "the enriched kind has no split call: femasm_assemble_system fills the send buffer");
   HIPCHK(hipSetDevice(p->device));
   const int bc = bcs ? bcs->kind : FEMASM_BC_NONE;
   if (bc < 0 || bc > 3) return fail(FEMASM_ERR_ARG, "unknown bc kind %d", bc);
@@ -942,6 +1136,7 @@ int femasm_assemble_interface(femasm_plan *p, const femasm_material *mat, const 
 int femasm_apply_operator(femasm_plan *p, const femasm_material *mat, const femasm_bc *bcs, const double *x,
                           double *y) {
   if (!p || !x || !y) return fail(FEMASM_ERR_ARG, "null argument");
+  if (p->kind == KIND_ENRICHED) return fail(FEMASM_ERR_ARG, "femasm_apply_operator: not offered for the enriched kind");
   HIPCHK(hipSetDevice(p->device));
   const int bc = bcs ? bcs->kind : FEMASM_BC_NONE;
   if (bc < 0 || bc > 3) return fail(FEMASM_ERR_ARG, "unknown bc kind %d", bc);
@@ -1011,6 +1206,8 @@ int femasm_apply_operator(femasm_plan *p, const femasm_material *mat, const fema
 int femasm_fill_properties(femasm_plan *p, double E, double nu, int32_t stride, double *gp_out) {
   if (!p || !gp_out) return fail(FEMASM_ERR_ARG, "null argument");
   if (p->kind == KIND_POISSON) return fail(FEMASM_ERR_ARG, "the Poisson driver has no property array");
+  if (p->kind == KIND_ENRICHED)
+    return fail(FEMASM_ERR_ARG, "the enrichment data of an enriched record is the caller's (no driver fills it, SURVEY section 0)");
   const int need = (p->kind == KIND_PLANE) ? 24 : 400;
   if (stride < need || stride > 416) return fail(FEMASM_ERR_ARG, "stride %d not in [%d, 416]", stride, need);
   HIPCHK(hipSetDevice(p->device));
@@ -1047,6 +1244,7 @@ static int grow(double **buf, int64_t *have, int64_t need) {
 int femasm_error_integrals(femasm_plan *p, const double *u, double sums[2]) {
   if (!p || !u || !sums) return fail(FEMASM_ERR_ARG, "null argument");
   if (p->kind == KIND_PLANE) return fail(FEMASM_ERR_ARG, "the reference has no error norms for the 2-D driver");
+  if (p->kind == KIND_ENRICHED) return fail(FEMASM_ERR_ARG, "femasm_error_integrals: not offered for the enriched kind");
   HIPCHK(hipSetDevice(p->device));
   sums[0] = sums[1] = 0.0;
   if (p->nel <= 0) return FEMASM_OK;
@@ -1083,6 +1281,7 @@ int femasm_error_integrals(femasm_plan *p, const double *u, double sums[2]) {
 int femasm_error_integrals_static(femasm_plan *p, const double *u, double *sums) {
   if (!p || !u || !sums) return fail(FEMASM_ERR_ARG, "null argument");
   if (p->kind == KIND_PLANE) return fail(FEMASM_ERR_ARG, "the reference has no error norms for the 2-D driver");
+  if (p->kind == KIND_ENRICHED) return fail(FEMASM_ERR_ARG, "femasm_error_integrals_static: not offered for the enriched kind");
   HIPCHK(hipSetDevice(p->device));
   if (!is_device_ptr(u) || !is_device_ptr(sums))
     return fail(FEMASM_ERR_ARG, "femasm_error_integrals_static takes DEVICE pointers (u and sums): staging would allocate");
@@ -1160,6 +1359,8 @@ int femasm_compress_bc_rows(femasm_plan *p, const femasm_bc *bcs, const double *
   const int bc = bcs ? bcs->kind : FEMASM_BC_NONE;
   // MatZeroRows is what the elastic drivers call (E2:794-799, S3:1513-1518); the Poisson driver never does: its
   // boundary rows are assembled (diagonal = number of elements sharing the node, P3:286-340) and stay in the pattern
+  if (p->kind == KIND_ENRICHED)
+    return fail(FEMASM_ERR_ARG, "femasm_compress_bc_rows: not offered for the enriched kind (blocked dofs depend on the records)");
   if (bc == FEMASM_BC_POISSON_INLOOP)
     return fail(FEMASM_ERR_ARG, "femasm_compress_bc_rows: the Poisson driver has no MatZeroRows step (its Dirichlet "
                 "rows are assembled in the element loop, diagonal = element valence)");
@@ -1276,7 +1477,8 @@ int femasm_coord_moments(femasm_plan *p, double mom[10]) {
 
 int femasm_rigid_body_modes(femasm_plan *p, const double mom[10], double *modes) {
   if (!p || !mom || !modes) return fail(FEMASM_ERR_ARG, "null argument");
-  if (p->kind == KIND_POISSON) return fail(FEMASM_ERR_ARG, "rigid-body modes belong to the elasticity kinds");
+  if (p->kind == KIND_POISSON || p->kind == KIND_ENRICHED)
+    return fail(FEMASM_ERR_ARG, "rigid-body modes belong to the elasticity kinds with 2 or 3 dofs per node");
   if (!(mom[0] >= 1.0)) return fail(FEMASM_ERR_ARG, "mom[0] (global node count) must be >= 1");
   HIPCHK(hipSetDevice(p->device));
   const Slab &s = p->s;

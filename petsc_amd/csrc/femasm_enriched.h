@@ -1,0 +1,454 @@
+// femasm_enriched.h -- config 5: SGFEM-enriched Q1 hexahedra (node-blocked D = 3 (1 + n_enr) dofs per node).
+//
+// The reference holds no arithmetic for this configuration: R3 has the bookkeeping only
+// (R3:39-49 macros and flags, R3:52-68 record, R3:1265-1269 zero fill, R3:1467-1595 dead BlockRedundantDofs).  The
+// specification is this build's own, DESIGN.md section 9 (the tests hold an independent CPU restatement of it).
+//
+// Scalar shape functions of an element: Phi_{a,0} = N_a, Phi_{a,1+m} = N_a phi_m with phi_m = psi_m - I_h psi_m
+// (SGFEM, `type` 1 of R3:42) or psi_m (GFEM); fn = 8 s + a.  Every 3x3 block of the element matrix is the S3 formula
+// (S3:450-518) on the gradients of two scalar functions, so the local matrix is (8 S)^2 such blocks.
+//
+// Two kernels (north_star (3) + (4): local B^T D B contraction, then a deterministic segmented reduction):
+//   k_enr_elem<S, MFMA>   one wave per element.  Lanes (Gauss point p, node a) build the gradient table
+//                         T[p][fn][3] and the w detJ scaled (D11, D12, D44) in LDS; then the contraction
+//                           VALU: lane = node pair (a, b), all S^2 (s,t) blocks of that pair, 21 FMAs per block and point
+//                           MFMA: S = 2 only: the 16 scalar functions are exactly one v_mfma_f64_16x16x4 tile; block
+//                                 (r,c) of all 256 function pairs = sum over the K index (p, term) of
+//                                 A = grad_r Phi_i, B = D12 grad_c Phi_j  and  A = grad_c Phi_i, B = D44 grad_r Phi_j
+//                                 (diagonal: D11 and two D44 terms): 42 MFMAs per element, operands straight from T
+//                         the element matrix goes to a scratch ring in the layout [element][a][q][b][r] (row node, row
+//                         dof, column node, column dof) through LDS, 16 B per lane, whole lines.
+//   k_enr_gather<D>       one wave per node: adds the <= 8 chunks [a] of the elements around the node (each a contiguous
+//                         8 D^2 doubles) into the node's CSR block in LDS, in the reference's element order
+//                         (k -> j -> i: MatSetValuesStencil ADD order, S3:687-705), applies the row rules (Dirichlet faces,
+//                         blocked redundant dofs) and writes the block, which is contiguous in the CSR array.
+// Every CSR value has one writer, no atomics on values, bitwise reproducible.
+#pragma once
+#include "femasm_kernels.h"
+
+namespace femasm {
+
+enum { KIND_ENRICHED = 3 };
+constexpr int ENR_MAX_S = 4;  // 1 + n_enr families supported by the instantiations below
+
+struct EnrArgs {
+  const double *coords;   // node layers [cks, cke)
+  const double *gp;       // R3 records + enrichment blocks, stride doubles per element (never null)
+  double *ke;             // element-matrix ring: slot = element layer % nring
+  double *out;            // gather: CSR values of the processed rows / b
+  double *elemF;          // RHS element vectors
+  unsigned long long *bad;
+  int64_t base_off;
+  int64_t cke;
+  int64_t L0, L1;         // k_enr_elem: element layers of this launch
+  int64_t s0, s1;         // gather: node layers of this launch
+  int32_t nring;
+  int32_t stride, base;   // record stride and width of the R3 part (408: 32-bit PetscInt, 416: 64-bit)
+  int32_t sgfem;          // 1: phi = psi - I_h psi (R3:42 `type` 1), 0: phi = psi
+  int32_t bc, iface;
+  double E, nu;           // FEMASM_MAT_UNIFORM is not offered for this kind (the enrichment data lives in the records)
+};
+
+__device__ inline int64_t enr_flag(const double *rec, int base, int idx) {
+  // PetscInt enrich_type[8], n_enrich[8] inside a struct of PetscScalar, at double 400 (R3:65-67)
+  if (base == 408) return (int64_t)reinterpret_cast<const int32_t *>(rec + 400)[idx];
+  return reinterpret_cast<const int64_t *>(rec + 400)[idx];
+}
+// number of active families at local node a of the element whose record is rec
+__device__ inline int enr_active(const double *rec, int base, int a, int n_enr) {
+  const int64_t t = enr_flag(rec, base, a), n = enr_flag(rec, base, 8 + a);
+  if (t == 0 || n <= 0) return 0;
+  return n < n_enr ? (int)n : n_enr;
+}
+
+template <int S> struct EnrCfg {
+  static constexpr int NF = 8 * S, D = 3 * S, KE = 64 * D * D;
+  static constexpr int NW = (S <= 2) ? 4 : (S == 3 ? 2 : 1);  // waves (= elements) per workgroup, bounded by the LDS staging
+};
+
+typedef double d4v __attribute__((ext_vector_type(4)));
+
+template <int S, bool MFMA>
+__global__ __launch_bounds__(64 * EnrCfg<S>::NW) void k_enr_elem(const Slab s, const EnrArgs a) {
+  using Cf = EnrCfg<S>;
+  constexpr int NF = Cf::NF, D = Cf::D, KE = Cf::KE, NW = Cf::NW, NE = S - 1;
+  static_assert(!MFMA || S == 2, "the FP64 MFMA contraction is the 16-function tile of one enrichment family");
+  __shared__ __attribute__((aligned(16))) double sh_ke[NW][KE];
+  __shared__ double sh_T[NW][8][NF][3];
+  __shared__ double sh_cf[NW][8][4];
+  __shared__ double sh_x[NW][24];
+  __shared__ double sh_en[NW][NE > 0 ? NE : 1][40];  // psi at nodes [8], at Gauss points [8], grad psi [8][3]
+  __shared__ int sh_act[NW][8];
+  __shared__ double sh_G[8][3][8], sh_N[8][8];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int t = tid; t < 192; t += 64 * NW) (&sh_G[0][0][0])[t] = (&c_tab3.G[0][0][0])[t];
+  for (int t = tid; t < 64; t += 64 * NW) (&sh_N[0][0])[t] = (&c_tab3.N[0][0])[t];
+  __syncthreads();  // (the only workgroup barrier: every wave is still here)
+
+  const int64_t M = s.dim[0], N = s.dim[1];
+  const int64_t mx = M - 1, my = N - 1;
+  const int64_t e = (int64_t)blockIdx.x * NW + w;  // element of this launch, k -> j -> i order
+  if (e >= mx * my * (a.L1 - a.L0)) return;
+  const int64_t ex = e % mx, ey = (e / mx) % my, ez = a.L0 + e / (mx * my);
+  const double *rec = a.gp + (ex + mx * (ey + my * (ez - s.mat_e_ks))) * (int64_t)a.stride;
+  auto wave_sync = [&]() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  // ---- inputs of the element -> LDS ----
+  if (lane < 24) {
+    const int n = lane / 3, d = lane - 3 * n;
+    const int64_t node = (ex + HDI[n]) + M * ((ey + HDJ[n]) + N * (ez + HDK[n] - s.cks));
+    sh_x[w][lane] = a.coords[3 * node + d];
+  }
+  if (lane < 8) sh_act[w][lane] = enr_active(rec, a.base, lane, NE);
+  if constexpr (NE > 0) {
+    if (lane < 40)
+#pragma unroll
+      for (int m = 0; m < NE; m++) sh_en[w][m][lane] = rec[a.base + 64 * m + lane];
+  }
+  wave_sync();
+
+  // ---- lanes (p, n): Jacobian of Gauss point p, physical gradient of N_n, scaled coefficients ----
+  const int p = lane >> 3, n = lane & 7;
+  double gN[3];
+  {
+    double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) J[r][c] = J[r][c] + sh_G[p][r][q] * sh_x[w][3 * q + c];
+    double iJ[3][3], det;
+    inv3_ref(J, iJ, det);
+    const double wJ = 1.0 * det;
+#pragma unroll
+    for (int k = 0; k < 3; k++) gN[k] = sh_G[p][0][n] * iJ[k][0] + sh_G[p][1][n] * iJ[k][1] + sh_G[p][2][n] * iJ[k][2];
+#pragma unroll
+    for (int k = 0; k < 3; k++) sh_T[w][p][n][k] = gN[k];
+    if (n == 0) {
+      if (!(wJ > 0.0)) atomicAdd(a.bad, 1ULL);
+      double d11, d12, d44;
+      scaled_coefs<KIND_ELASTIC>(rec[96 + p], rec[104 + p], wJ, d11, d12, d44);
+      sh_cf[w][p][0] = d11;
+      sh_cf[w][p][1] = d12;
+      sh_cf[w][p][2] = d44;
+    }
+  }
+  if constexpr (NE > 0) {
+    wave_sync();  // the gradients of all eight N_b at p are in T
+    const int nact = sh_act[w][n];
+    const double Nn = sh_N[p][n];
+#pragma unroll
+    for (int m = 0; m < NE; m++) {
+      const double *en = sh_en[w][m];
+      double phi = en[8 + p], dphi[3] = {en[16 + 3 * p], en[16 + 3 * p + 1], en[16 + 3 * p + 2]};
+      if (a.sgfem) {
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+          phi = phi - sh_N[p][b] * en[b];
+#pragma unroll
+          for (int k = 0; k < 3; k++) dphi[k] = dphi[k] - sh_T[w][p][b][k] * en[b];
+        }
+      }
+      const bool on = m < nact;
+#pragma unroll
+      for (int k = 0; k < 3; k++) sh_T[w][p][8 * (1 + m) + n][k] = on ? phi * gN[k] + Nn * dphi[k] : 0.0;
+    }
+  }
+  wave_sync();
+
+  // ---- contraction: 3x3 block of every pair of scalar functions, into the staging area in scratch order ----
+  double *ke = sh_ke[w];
+  if constexpr (!MFMA) {
+    const int na = lane >> 3, nb = lane & 7;  // node pair (a, b)
+#pragma unroll 1
+    for (int sa = 0; sa < S; sa++) {
+      double acc[S][9];
+#pragma unroll
+      for (int t = 0; t < S; t++)
+#pragma unroll
+        for (int q = 0; q < 9; q++) acc[t][q] = 0.0;
+#pragma unroll 1
+      for (int q = 0; q < 8; q++) {
+        const double d11 = sh_cf[w][q][0], d12 = sh_cf[w][q][1], d44 = sh_cf[w][q][2];
+        const double *ga = sh_T[w][q][8 * sa + na];
+        double l[3], m[3], qq[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          l[k] = d12 * ga[k];
+          m[k] = d44 * ga[k];
+          qq[k] = d11 * ga[k];
+        }
+#pragma unroll
+        for (int t = 0; t < S; t++) {
+          const double *gbp = sh_T[w][q][8 * t + nb];
+          const double gb[3] = {gbp[0], gbp[1], gbp[2]};
+          add_block<KIND_ELASTIC, 3>(acc[t], l, m, qq, gb);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < S; t++)
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+          for (int cc = 0; cc < 3; cc++) ke[((na * D + 3 * sa + c) * 8 + nb) * D + 3 * t + cc] = acc[t][3 * c + cc];
+    }
+  } else {
+    // lane l: function fn = l & 15 (both operands), Gauss points p = (l >> 4) + 4 h of K-step h
+    const int fn = lane & 15, pq = lane >> 4;
+    double ag[2][3], b11[2][3], b12[2][3], b44[2][3];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int q = pq + 4 * h;
+      const double d11 = sh_cf[w][q][0], d12 = sh_cf[w][q][1], d44 = sh_cf[w][q][2];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const double g = sh_T[w][q][fn][k];
+        ag[h][k] = g;
+        b11[h][k] = d11 * g;
+        b12[h][k] = d12 * g;
+        b44[h][k] = d44 * g;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        d4v acc = {0.0, 0.0, 0.0, 0.0};
+        if (r != c) {
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[h][r], b12[h][c], acc, 0, 0, 0);  // D12 g_i[r] g_j[c]
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[h][c], b44[h][r], acc, 0, 0, 0);  // D44 g_i[c] g_j[r]
+          }
+        } else {
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[h][r], b11[h][r], acc, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+              if (k != r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[h][k], b44[h][k], acc, 0, 0, 0);
+          }
+        }
+        // result register g of lane l: row function i = (l >> 4) + 4 g, column function j = l & 15
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const int i = pq + 4 * g, sa = i >> 3, na = i & 7, t = fn >> 3, nb = fn & 7;
+          ke[((na * D + 3 * sa + r) * 8 + nb) * D + 3 * t + c] = acc[g];
+        }
+      }
+  }
+  wave_sync();
+
+  // ---- staging -> scratch ring, 16 B per lane, whole lines (KE * 8 bytes is a multiple of 128) ----
+  const int slot = (int)(ez % a.nring);
+  double2 *dst = reinterpret_cast<double2 *>(a.ke + ((slot * my + ey) * mx + ex) * (int64_t)KE);
+  const double2 *src = reinterpret_cast<const double2 *>(ke);
+#pragma unroll 2
+  for (int t = lane; t < KE / 2; t += 64) dst[t] = src[t];
+}
+
+// ---------------------------------------------------------------------------
+// Segmented reduction: one wave per node of node layers [s0, s1).  D is a runtime number here (3 ... 12).
+// ---------------------------------------------------------------------------
+constexpr int ENR_GW = 4;  // waves per workgroup
+template <int DMAX>
+__global__ __launch_bounds__(64 * ENR_GW) void k_enr_gather(const Slab s, const EnrArgs a) {
+  __shared__ double sh_acc[ENR_GW][27 * DMAX * DMAX];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t M = s.dim[0], N = s.dim[1], P = s.dim[2];
+  const int D = s.dof;
+  const int64_t q = (int64_t)blockIdx.x * ENR_GW + w;
+  if (q >= M * N * (a.s1 - a.s0)) return;
+  const int64_t i = q % M, j = (q / M) % N, k = a.s0 + q / (M * N);
+  const int64_t mx = M - 1, my = N - 1;
+  const int cntx = span1(i, M), cnty = span1(j, N), cntz = span1(k, P);
+  const int rowlen = cntx * cnty * cntz * D, nvals = D * rowlen, KN = 8 * D * D;
+  const int xi0 = (i == 0), yi0 = (j == 0), zi0 = (k == 0);
+  double *acc = sh_acc[w];
+  auto wave_sync = [&]() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  };
+  for (int t = lane; t < nvals; t += 64) acc[t] = 0.0;
+  wave_sync();
+  const bool dirichlet = (a.bc == BC_S3) && on_boundary(s, i, j, k);
+  if (!dirichlet) {
+#pragma unroll 1
+    for (int oz = -1; oz <= 0; oz++)
+#pragma unroll 1
+      for (int oy = -1; oy <= 0; oy++)
+#pragma unroll 1
+        for (int ox = -1; ox <= 0; ox++) {  // elements in the reference's loop order (S3:687-689)
+          const int64_t ex = i + ox, ey = j + oy, ez = k + oz;
+          if (ex < 0 || ex >= mx || ey < 0 || ey >= my || ez < s.els || ez >= s.ele) continue;
+          const int al = hex_idx(-ox, -oy, -oz);
+          const int slot = (int)(ez % a.nring);
+          const double *chunk = a.ke + (((slot * my + ey) * mx + ex) * (int64_t)8 + al) * KN;
+          for (int t = lane; t < KN; t += 64) {
+            const int qr = t / (8 * D), rem = t - qr * 8 * D, b = rem / D, r = rem - b * D;
+            const int dx = ox + HDI[b], dy = oy + HDJ[b], dz = oz + HDK[b];
+            const int nbr = ((dz + 1 - zi0) * cnty + (dy + 1 - yi0)) * cntx + (dx + 1 - xi0);
+            const int pos = qr * rowlen + nbr * D + r;
+            acc[pos] = acc[pos] + chunk[t];
+          }
+          wave_sync();  // the next element's read-modify-writes come after these
+        }
+  }
+  // row rules: Dirichlet faces (all dofs of the node), blocked redundant dofs (enriched dofs of inactive families)
+  const int self = (((k > 0) * cnty + (j > 0)) * cntx + (i > 0)) * D;
+  int nact = 0;
+  if (!dirichlet && D > 3 && !a.iface) {
+    const int64_t bx = i > 0 ? i - 1 : 0, by = j > 0 ? j - 1 : 0, bz = k > 0 ? k - 1 : 0;  // the element behind the node
+    const double *rec = a.gp + (bx + mx * (by + my * (bz - s.mat_e_ks))) * (int64_t)a.stride;
+    nact = enr_active(rec, a.base, hex_idx(i > 0, j > 0, k > 0), D / 3 - 1);
+  }
+  const double diag = a.iface ? 0.0 : 1.0;
+  if (dirichlet || (D > 3 && !a.iface)) {
+    for (int t = lane; t < nvals; t += 64) {
+      const int qr = t / rowlen, c = t - qr * rowlen;
+      const bool unit = dirichlet || (qr >= 3 && (qr / 3 - 1) >= nact);
+      if (unit) acc[t] = (c == self + qr) ? diag : 0.0;
+    }
+  }
+  wave_sync();
+  double *o = a.out + (row_start(s, i, j, k, 0) - a.base_off);
+  for (int t = lane; t < nvals; t += 64) o[t] = acc[t];
+}
+
+// ---------------------------------------------------------------------------
+// RHS of the enriched element (S3:520-656 with Phi_{a,s} in place of N_a): one thread per element -> element
+// vectors (blocks of 16 elements x 8 D lines, as ef_idx), then one thread per node.
+// ---------------------------------------------------------------------------
+__device__ inline int64_t ef_idx_rt(int64_t e, int t, int nout) { return (e >> 4) * ((int64_t)nout * 16) + t * 16 + (e & 15); }
+
+template <int S>
+__global__ __launch_bounds__(128) void k_enr_rhs_elem(const Slab s, const EnrArgs a, int64_t nel) {
+  constexpr int D = 3 * S, NE = S - 1;
+  const int64_t e = (int64_t)blockIdx.x * 128 + threadIdx.x;
+  if (e >= nel) return;
+  const int64_t M = s.dim[0], N = s.dim[1];
+  const int64_t mx = M - 1, my = N - 1;
+  const int64_t ex = e % mx, ey = (e / mx) % my, ez = s.els + e / (mx * my);
+  const double *rec = a.gp + (ex + mx * (ey + my * (ez - s.mat_e_ks))) * (int64_t)a.stride;
+  double xc[24];
+#pragma unroll
+  for (int n = 0; n < 8; n++) {
+    const int64_t node = (ex + HDI[n]) + M * ((ey + HDJ[n]) + N * (ez + HDK[n] - s.cks));
+#pragma unroll
+    for (int d = 0; d < 3; d++) xc[3 * n + d] = a.coords[3 * node + d];
+  }
+  int nact[8];
+#pragma unroll
+  for (int n = 0; n < 8; n++) nact[n] = enr_active(rec, a.base, n, NE);
+  double F[8 * D];
+#pragma unroll
+  for (int t = 0; t < 8 * D; t++) F[t] = 0.0;
+  // body force at the volume Gauss points
+  for (int p = 0; p < 8; p++) {
+    const double fac = 1.0 * det3_only(c_tab3.G[p], xc);
+    const double f[3] = {rec[160 + p], rec[168 + p], rec[176 + p]};
+    double phi[S];
+    phi[0] = 1.0;
+#pragma unroll
+    for (int m = 0; m < NE; m++) {
+      const double *en = rec + a.base + 64 * m;
+      double v = en[8 + p];
+      if (a.sgfem)
+#pragma unroll
+        for (int b = 0; b < 8; b++) v = v - c_tab3.N[p][b] * en[b];
+      phi[1 + m] = v;
+    }
+#pragma unroll
+    for (int n = 0; n < 8; n++)
+#pragma unroll
+      for (int sa = 0; sa < S; sa++) {
+        const double val = (sa == 0 || sa - 1 < nact[n]) ? c_tab3.N[p][n] * phi[sa] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; c++) F[n * D + 3 * sa + c] += fac * val * f[c];
+      }
+  }
+  // natural-BC term over the 24 face points of the element (S3:548-656)
+  const double dx = fabs(xc[0] - xc[9]), dy = fabs(xc[1] - xc[4]), dz = fabs(xc[2] - xc[14]);
+  const double *gx = rec + 184, *gy = rec + 256, *gz = rec + 328, *EB = rec + 112, *nuB = rec + 136;
+  for (int p = 0; p < 24; p++) {
+    const double pe = EB[p], pn = nuB[p];
+    const double factor = pe * (1 - pn) / ((1.0 + pn) * (1.0 - 2.0 * pn));
+    const double d11 = factor * 1.0, d12 = factor * (pn / (1 - pn)), d44 = factor * (0.5 * (1 - 2 * pn) / (1 - pn));
+    const double e0 = gx[3 * p], e1 = gy[3 * p + 1], e2 = gz[3 * p + 2];
+    const double e3 = gx[3 * p + 1] + gy[3 * p], e4 = gy[3 * p + 2] + gz[3 * p + 1], e5 = gx[3 * p + 2] + gz[3 * p];
+    const double z0 = d11 * e0 + d12 * e1 + d12 * e2;
+    const double z1 = d12 * e0 + d11 * e1 + d12 * e2;
+    const double z2 = d12 * e0 + d12 * e1 + d11 * e2;
+    const double z3 = d44 * e3, z4 = d44 * e4, z5 = d44 * e5;
+    const int axis = p / 8;
+    const double side = ((p / 4) % 2 == 0) ? 1.0 : -1.0;
+    double sn[3], Jp;
+    if (axis == 0)      { sn[0] = z0 * side; sn[1] = z3 * side; sn[2] = z5 * side; Jp = (0.5 * dy) * (0.5 * dz); }
+    else if (axis == 1) { sn[0] = z3 * side; sn[1] = z1 * side; sn[2] = z4 * side; Jp = (0.5 * dx) * (0.5 * dz); }
+    else                { sn[0] = z5 * side; sn[1] = z4 * side; sn[2] = z2 * side; Jp = (0.5 * dx) * (0.5 * dy); }
+    const double fac = 1.0 * Jp;
+    double phi[S];
+    phi[0] = 1.0;
+#pragma unroll
+    for (int m = 0; m < NE; m++) {
+      const double *en = rec + a.base + 64 * m;
+      double v = en[40 + p];
+      if (a.sgfem)
+#pragma unroll
+        for (int b = 0; b < 8; b++) v = v - c_tab3.NF[p][b] * en[b];
+      phi[1 + m] = v;
+    }
+#pragma unroll
+    for (int n = 0; n < 8; n++)
+#pragma unroll
+      for (int sa = 0; sa < S; sa++) {
+        const double val = (sa == 0 || sa - 1 < nact[n]) ? c_tab3.NF[p][n] * phi[sa] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; c++) F[n * D + 3 * sa + c] += fac * val * sn[c];
+      }
+  }
+#pragma unroll
+  for (int t = 0; t < 8 * D; t++) a.elemF[ef_idx_rt(e, t, 8 * D)] = F[t];
+}
+
+// one thread per (node, dof) of node layers [s0, s1): element contributions in k -> j -> i order, then the row rules
+__global__ __launch_bounds__(256) void k_enr_rhs_gather(const Slab s, const EnrArgs a) {
+  const int64_t M = s.dim[0], N = s.dim[1];
+  const int D = s.dof;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= M * N * (a.s1 - a.s0) * D) return;
+  const int qd = (int)(t % D);
+  const int64_t nq = t / D;
+  const int64_t i = nq % M, j = (nq / M) % N, k = a.s0 + nq / (M * N);
+  const int64_t mx = M - 1, my = N - 1;
+  double b = 0.0;
+  for (int oz = -1; oz <= 0; oz++)
+    for (int oy = -1; oy <= 0; oy++)
+      for (int ox = -1; ox <= 0; ox++) {
+        const int64_t ex = i + ox, ey = j + oy, ez = k + oz;
+        if (ex < 0 || ex >= mx || ey < 0 || ey >= my || ez < s.els || ez >= s.ele) continue;
+        const int64_t e = ex + mx * (ey + my * (ez - s.els));
+        b = b + a.elemF[ef_idx_rt(e, hex_idx(-ox, -oy, -oz) * D + qd, 8 * D)];
+      }
+  const bool dirichlet = (a.bc == BC_S3) && on_boundary(s, i, j, k);
+  if (dirichlet) {
+    if (a.iface) b = 0.0;
+    else if (qd == 2) {
+      constexpr double PI = 3.14159265358979323846264338327950288;
+      const int64_t node = i + M * (j + N * (k - s.cks));
+      b = sin(PI * a.coords[3 * node]) * sin(PI * a.coords[3 * node + 1]) * sin(PI * a.coords[3 * node + 2]);
+    } else b = 0.0;  // S3:964-968 for the displacement dofs; enriched dofs of a Dirichlet node: 0
+  } else if (qd >= 3 && !a.iface) {
+    const int64_t bx = i > 0 ? i - 1 : 0, by = j > 0 ? j - 1 : 0, bz = k > 0 ? k - 1 : 0;
+    const double *rec = a.gp + (bx + mx * (by + my * (bz - s.mat_e_ks))) * (int64_t)a.stride;
+    if (qd / 3 - 1 >= enr_active(rec, a.base, hex_idx(i > 0, j > 0, k > 0), D / 3 - 1)) b = 0.0;  // blocked dof
+  }
+  a.out[t] = b;
+}
+
+}  // namespace femasm

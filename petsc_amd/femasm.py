@@ -16,7 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FEMASM_LIB", os.path.join(_HERE, "csrc", "libfemasm.so"))  # override: kernel experiments
 
-POISSON3D_Q1, PLANE_STRAIN2D_Q1, ELASTIC3D_Q1 = 0, 1, 2
+POISSON3D_Q1, PLANE_STRAIN2D_Q1, ELASTIC3D_Q1, ELASTIC3D_ENRICHED = 0, 1, 2, 3
 MAT_AOS, MAT_UNIFORM = 0, 1
 BC_NONE, BC_POISSON_INLOOP, BC_E2_COMPRESSION, BC_S3_ALLFACES_EXACT = 0, 1, 2, 3
 
@@ -24,6 +24,7 @@ _TRAITS = {  # kind: (nsd, dof, nen, ngp)
     POISSON3D_Q1: (3, 1, 8, 8),
     PLANE_STRAIN2D_Q1: (2, 2, 4, 4),
     ELASTIC3D_Q1: (3, 3, 8, 8),
+    ELASTIC3D_ENRICHED: (3, 3, 8, 8),  # dof = 3 (1 + n_enr), set per plan
 }
 
 EXPORTS = [
@@ -32,7 +33,7 @@ EXPORTS = [
     "femasm_interface_set_buffers", "femasm_interface_apply", "femasm_compress_bc_rows", "femasm_plan_sync", "femasm_last_error",
     "femasm_version", "femasm_plan_set_fast_path", "femasm_plan_get_fast_path", "femasm_assemble_interface", "femasm_error_integrals", "femasm_fill_properties", "femasm_apply_operator",
     "femasm_coo_indices", "femasm_coord_moments", "femasm_rigid_body_modes", "femasm_zero_rows",
-    "femasm_error_integrals_static",
+    "femasm_error_integrals_static", "femasm_plan_set_enriched_contraction",
 ]
 
 
@@ -43,14 +44,14 @@ class FemasmError(RuntimeError):
 
 
 class Mesh(C.Structure):
-    _fields_ = [("problem", C.c_int32), ("reserved", C.c_int32), ("M", C.c_int64), ("N", C.c_int64),
+    _fields_ = [("problem", C.c_int32), ("n_enr", C.c_int32), ("M", C.c_int64), ("N", C.c_int64),
                 ("P", C.c_int64), ("ks", C.c_int64), ("ke", C.c_int64), ("cks", C.c_int64), ("cke", C.c_int64),
                 ("coords", C.c_void_p)]
 
 
 class Material(C.Structure):
     _fields_ = [("layout", C.c_int32), ("stride", C.c_int32), ("e_ks", C.c_int64), ("gp", C.c_void_p),
-                ("E", C.c_double), ("nu", C.c_double)]
+                ("E", C.c_double), ("nu", C.c_double), ("enr_mode", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Quad(C.Structure):
@@ -120,9 +121,12 @@ def _check(rc):
 class Plan:
     """One slab of the structured (DMDA) mesh on one GPU."""
 
-    def __init__(self, problem, M, N, P=1, coords=None, ks=0, ke=None, cks=None, cke=None, device=0):
+    def __init__(self, problem, M, N, P=1, coords=None, ks=0, ke=None, cks=None, cke=None, device=0, n_enr=0):
         lib = load()
         nsd, dof, nen, ngp = _TRAITS[problem]
+        if problem == ELASTIC3D_ENRICHED:
+            dof = 3 * (1 + n_enr)
+        self.n_enr = n_enr
         SL = P if nsd == 3 else N
         ke = SL if ke is None else ke
         cks = (max(ks - 1, 0)) if cks is None else cks
@@ -131,7 +135,7 @@ class Plan:
         self.nsd, self.dof, self.nen, self.ngp = nsd, dof, nen, ngp
         self.ks, self.ke, self.cks, self.cke = ks, ke, cks, cke
         self._coords = coords  # keep alive
-        mesh = Mesh(problem, 0, M, N, self.P, ks, ke, cks, cke, _ptr(coords))
+        mesh = Mesh(problem, n_enr, M, N, self.P, ks, ke, cks, cke, _ptr(coords))
         quad = Quad(ngp, 0)
         h = C.c_void_p()
         _check(lib.femasm_plan_create(C.byref(mesh), C.byref(quad), C.c_int(device), C.byref(h)))
@@ -181,14 +185,18 @@ class Plan:
         _check(load().femasm_scatter_map(self._h, _ptr(out)))
         return out.reshape(self.nel, nr, nr)
 
+    def set_enriched_contraction(self, mode):
+        """-1 default, 0 FP64 VALU, 1 FP64 MFMA (n_enr = 1)."""
+        _check(load().femasm_plan_set_enriched_contraction(self._h, C.c_int(int(mode))))
+
     def assemble_system(self, values, b, material=None, bc=BC_NONE, E=0.0, nu=0.0, stride=0, e_ks=None,
-                        want_stats=False):
+                        want_stats=False, enr_mode=0):
         """values / b: numpy (host) or torch (device) float64 buffers, or None.
         material: AoS GaussPointCoefficients array (numpy/torch) or None for uniform E, nu."""
         if material is None:
             mat = Material(MAT_UNIFORM, 0, 0, None, E, nu)
         else:
-            mat = Material(MAT_AOS, stride, self.els if e_ks is None else e_ks, _ptr(material), E, nu)
+            mat = Material(MAT_AOS, stride, self.els if e_ks is None else e_ks, _ptr(material), E, nu, enr_mode, 0)
         bcs = BC(bc, 0)
         st = Stats()
         _check(load().femasm_assemble_system(self._h, C.byref(mat), C.byref(bcs), _ptr(values), _ptr(b),
