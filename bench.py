@@ -29,7 +29,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="elastic3d", choices=["elastic3d", "poisson3d", "elastic2d"])
+    ap.add_argument("--workload", default="elastic3d", choices=["elastic3d", "poisson3d", "elastic2d", "enriched3d"])
+    ap.add_argument("--n-enr", type=int, default=1, help="enriched3d: enrichment families per node (dof = 3(1+n_enr))")
+    ap.add_argument("--enr-contraction", default="default", choices=["default", "valu", "mfma"],
+                    help="enriched3d: local B^T D B contraction on FP64 VALU or v_mfma_f64_16x16x4 (n_enr = 1)")
     ap.add_argument("--nel", type=int, default=0, help="elements per direction (default: 128 / 256 / 2048)")
     ap.add_argument("--perturb", action="store_true", help="general (non-affine) geometry variant")
     ap.add_argument("--uniform-material", action="store_true", help="uniform E,nu instead of the AoS array")
@@ -92,6 +95,19 @@ def cpu_baseline(workload):
         O.bc_s3(M, M, M, coords, rp, ci, K, b)
         dt = time.perf_counter() - t0
         nel, sample = n ** 3, "64^3 sub-mesh of the 128^3 workload (K + b + BC), scaled per element"
+    elif workload == "enriched3d":
+        n = 10
+        M = n + 1
+        coords = O.uniform_coords(3, M, M, M)
+        psi = [lambda x, y, z: (x * x + 0.5 * y * z + 0.25 * z, 2 * x, 0.5 * z, 0.5 * y + 0.25)]
+        props = O.props_enriched(n, n, n, coords, 1, psi)
+        rp, ci = O.pattern(3, 6, M, M, M)
+        t0 = time.perf_counter()
+        K, b = O.assemble_enriched3d(M, M, M, coords, props, rp, ci, 1)
+        O.bc_enriched3d(M, M, M, coords, props, rp, ci, K, b, 1)
+        dt = time.perf_counter() - t0
+        nel, sample = n ** 3, ("10^3 sub-mesh of the 128^3 enriched workload, n_enr = 1 (naive 48x48 B^T D B per Gauss "
+                               "point as S3:507-515 would do it; no reference code exists for this configuration)")
     elif workload == "poisson3d":
         n = 160
         M = n + 1
@@ -184,6 +200,11 @@ def main():
         kind, nsd, dof, ngp, bc, stride = F.ELASTIC3D_Q1, 3, 3, 8, F.BC_S3_ALLFACES_EXACT, 400
         nel = args.nel or 128
         ref = "SGFEM/SGFEM_elastic3D.cpp"
+    elif wl == "enriched3d":
+        kind, nsd, dof, ngp, bc = F.ELASTIC3D_ENRICHED, 3, 3 * (1 + args.n_enr), 8, F.BC_S3_ALLFACES_EXACT
+        stride = 408 + 64 * args.n_enr
+        nel = args.nel or 128
+        ref = "SGFEM_real/SGFEM_elastic3D.cpp (enriched; specification of this engine)"
     elif wl == "poisson3d":
         kind, nsd, dof, ngp, bc, stride = F.POISSON3D_Q1, 3, 1, 8, F.BC_POISSON_INLOOP, 0
         nel = args.nel or 256
@@ -208,12 +229,17 @@ def main():
     if args.perturb:
         coords = synth.perturb_coords(coords, nsd, M, N, P, k0=cks)
     material = None
-    E, nu = (90.0, 0.28) if wl == "elastic3d" else (1.0, 0.33)
+    E, nu = (90.0, 0.28) if wl in ("elastic3d", "enriched3d") else (1.0, 0.33)
 
-    plan = F.Plan(kind, M, N, P, coords=coords, ks=ks, ke=ke, cks=cks, cke=cke, device=local_rank)
+    plan = F.Plan(kind, M, N, P, coords=coords, ks=ks, ke=ke, cks=cks, cke=cke, device=local_rank,
+                  n_enr=args.n_enr if wl == "enriched3d" else 0)
     plan.set_stream(torch.cuda.current_stream().cuda_stream)
     plan.set_fast_path(args.fast_level)
-    if wl != "poisson3d" and not args.uniform_material:
+    if wl == "enriched3d":
+        if args.enr_contraction != "default":
+            plan.set_enriched_contraction(1 if args.enr_contraction == "mfma" else 0)
+        material = synth.props_enriched(M, N, P, coords, n_enr=args.n_enr, e0=els, e1=ele, ck0=cks, E=E, nu=nu)
+    elif wl != "poisson3d" and not args.uniform_material:
         # the drivers' GaussPointCoefficients fill (S3:1243-1363 / E2:618-670), on device (row N1)
         material = torch.empty(plan.nel * stride, dtype=torch.float64, device=dev)
         plan.fill_properties(material, E, nu, stride)
@@ -231,6 +257,17 @@ def main():
 
     def step(collect):
         reqs = None
+        if world > 1 and wl == "enriched3d":
+            # (no split call for the enriched kind: the send buffer is filled by the assembly itself)
+            st = plan.assemble_system(vals, b, material=material, stride=stride, bc=bc, e_ks=els, want_stats=True)
+            if args.backend != "nccl":
+                plan.sync()
+            slab.exchange_interface(send if rank > 0 else None, recv if rank < world - 1 else None, rank, world)
+            plan.interface_apply(vals, b, bc=bc)
+            if collect:
+                k_ms.append(st.ms_kernel_K)
+                main_ms.append(st.ms_kernel_main)
+            return st
         if world > 1:
             # the rows owed to the rank below first, so that their transfer overlaps the bulk of the assembly
             plan.assemble_interface(material=material, stride=stride, bc=bc, E=E, nu=nu, e_ks=els)
@@ -277,11 +314,14 @@ def main():
         gco = synth.uniform_coords(nsd, M, N, P, device=dev)
         if args.perturb:
             gco = synth.perturb_coords(gco, nsd, M, N, P)
-        gplan = F.Plan(kind, M, N, P, coords=gco, device=local_rank)
+        gplan = F.Plan(kind, M, N, P, coords=gco, device=local_rank, n_enr=args.n_enr if wl == "enriched3d" else 0)
         gmat = None
         if material is not None:
-            gmat = torch.empty(gplan.nel * stride, dtype=torch.float64, device=dev)
-            gplan.fill_properties(gmat, E, nu, stride)
+            if wl == "enriched3d":
+                gmat = synth.props_enriched(M, N, P, gco, n_enr=args.n_enr, E=E, nu=nu)
+            else:
+                gmat = torch.empty(gplan.nel * stride, dtype=torch.float64, device=dev)
+                gplan.fill_properties(gmat, E, nu, stride)
         gv = torch.empty(gplan.nnz, dtype=torch.float64, device=dev)
         gb = torch.empty(gplan.nrows, dtype=torch.float64, device=dev)
         gplan.assemble_system(gv, gb, material=gmat, stride=stride, bc=bc, E=E, nu=nu)
@@ -310,7 +350,10 @@ def main():
         else:
             achieved = None
         level = plan.fast_path()
-        if wl == "elastic2d":
+        if wl == "enriched3d":
+            mode = args.enr_contraction if args.enr_contraction != "default" else ("mfma" if args.n_enr == 1 else "valu")
+            kernel = f"k_enr_elem<S={1 + args.n_enr},{mode}> + k_enr_gather (all of K)"
+        elif wl == "elastic2d":
             kernel = "k_assemble_e2_rect" if level == 2 else "k_assemble_rows<PLANE_STRAIN2D>"
         else:
             kname = "ELASTIC3D" if wl == "elastic3d" else "POISSON3D"

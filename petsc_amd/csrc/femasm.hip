@@ -537,9 +537,9 @@ int assemble_enriched(femasm_plan *p, const femasm_material *mat, int bc, double
       g.base_off = iface ? row_start(s, 0, 0, l0, 0) : 0;  // owned rows: positions relative to the slab's first row
       const int64_t nn = M * N * (l1 - l0);
       const dim3 grid((unsigned)((nn + ENR_GW - 1) / ENR_GW));
-      if (D <= 3) hipLaunchKernelGGL(k_enr_gather<3>, grid, dim3(64 * ENR_GW), 0, p->stream, s, g);
-      else if (D <= 6) hipLaunchKernelGGL(k_enr_gather<6>, grid, dim3(64 * ENR_GW), 0, p->stream, s, g);
-      else if (D <= 9) hipLaunchKernelGGL(k_enr_gather<9>, grid, dim3(64 * ENR_GW), 0, p->stream, s, g);
+      if (D == 3) hipLaunchKernelGGL(k_enr_gather<3>, grid, dim3(64 * ENR_GW), 0, p->stream, s, g);
+      else if (D == 6) hipLaunchKernelGGL(k_enr_gather<6>, grid, dim3(64 * ENR_GW), 0, p->stream, s, g);
+      else if (D == 9) hipLaunchKernelGGL(k_enr_gather<9>, grid, dim3(64 * ENR_GW), 0, p->stream, s, g);
       else hipLaunchKernelGGL(k_enr_gather<12>, grid, dim3(64 * ENR_GW), 0, p->stream, s, g);
     };
     if (M * N * (s.ke - s.ks + 1) / ENR_GW >= ((int64_t)1 << 31)) return fail(FEMASM_ERR_ARG, "slab too large for one launch");
@@ -569,12 +569,23 @@ int assemble_enriched(femasm_plan *p, const femasm_material *mat, int bc, double
   if (stats) HIPCHK(hipEventRecord(p->ev[1], p->stream));
   if (b) {
     if (p->nel > 0) {
-      const dim3 grid((unsigned)((p->nel + 127) / 128));
-      switch (S) {
-        case 1: hipLaunchKernelGGL(k_enr_rhs_elem<1>, grid, dim3(128), 0, p->stream, s, a, p->nel); break;
-        case 2: hipLaunchKernelGGL(k_enr_rhs_elem<2>, grid, dim3(128), 0, p->stream, s, a, p->nel); break;
-        case 3: hipLaunchKernelGGL(k_enr_rhs_elem<3>, grid, dim3(128), 0, p->stream, s, a, p->nel); break;
-        default: hipLaunchKernelGGL(k_enr_rhs_elem<4>, grid, dim3(128), 0, p->stream, s, a, p->nel); break;
+      static const bool simple = getenv("FEMASM_ENR_RHS_SIMPLE") != nullptr;  // the thread-per-element statement of the formulas
+      if (simple) {
+        const dim3 grid((unsigned)((p->nel + 127) / 128));
+        switch (S) {
+          case 1: hipLaunchKernelGGL(k_enr_rhs_elem<1>, grid, dim3(128), 0, p->stream, s, a, p->nel); break;
+          case 2: hipLaunchKernelGGL(k_enr_rhs_elem<2>, grid, dim3(128), 0, p->stream, s, a, p->nel); break;
+          case 3: hipLaunchKernelGGL(k_enr_rhs_elem<3>, grid, dim3(128), 0, p->stream, s, a, p->nel); break;
+          default: hipLaunchKernelGGL(k_enr_rhs_elem<4>, grid, dim3(128), 0, p->stream, s, a, p->nel); break;
+        }
+      } else {
+        const dim3 grid((unsigned)((p->nel + 31) / 32));  // 4 waves x 8 elements
+        switch (S) {
+          case 1: hipLaunchKernelGGL(k_enr_rhs_elem8<1>, grid, dim3(256), 0, p->stream, s, a, p->nel); break;
+          case 2: hipLaunchKernelGGL(k_enr_rhs_elem8<2>, grid, dim3(256), 0, p->stream, s, a, p->nel); break;
+          case 3: hipLaunchKernelGGL(k_enr_rhs_elem8<3>, grid, dim3(256), 0, p->stream, s, a, p->nel); break;
+          default: hipLaunchKernelGGL(k_enr_rhs_elem8<4>, grid, dim3(256), 0, p->stream, s, a, p->nel); break;
+        }
       }
     }
     auto rgather = [&](double *out, int64_t l0, int64_t l1, int iface) {

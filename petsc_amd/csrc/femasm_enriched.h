@@ -16,8 +16,12 @@
 //                                 (r,c) of all 256 function pairs = sum over the K index (p, term) of
 //                                 A = grad_r Phi_i, B = D12 grad_c Phi_j  and  A = grad_c Phi_i, B = D44 grad_r Phi_j
 //                                 (diagonal: D11 and two D44 terms): 42 MFMAs per element, operands straight from T
-//                         the element matrix goes to a scratch ring in the layout [element][a][q][b][r] (row node, row
-//                         dof, column node, column dof) through LDS, 16 B per lane, whole lines.
+//                         the element matrix goes to a scratch ring in the layout [element][a][s][r][c][j]: row node a, row
+//                         family s, row component r, column component c, column function j = 8 t + b -- a row node's
+//                         chunk is 8 D^2 contiguous doubles and, for S = 2, every (s, r, c) is one 128-byte line of 16
+//                         column functions, which is exactly what 16 lanes of an MFMA result register (or of the VALU
+//                         variant, which uses the same lane map) hold: each store instruction writes four whole lines
+//                         straight from registers, no staging.  Other S: through LDS, 16 B per lane.
 //   k_enr_gather<D>       one wave per node: adds the <= 8 chunks [a] of the elements around the node (each a contiguous
 //                         8 D^2 doubles) into the node's CSR block in LDS, in the reference's element order
 //                         (k -> j -> i: MatSetValuesStencil ADD order, S3:687-705), applies the row rules (Dirichlet faces,
@@ -63,8 +67,11 @@ __device__ inline int enr_active(const double *rec, int base, int a, int n_enr) 
 
 template <int S> struct EnrCfg {
   static constexpr int NF = 8 * S, D = 3 * S, KE = 64 * D * D;
+  static constexpr bool DIRECT = (S == 2);  // results go from registers to the ring (see the layout note above)
   static constexpr int NW = (S <= 2) ? 4 : (S == 3 ? 2 : 1);  // waves (= elements) per workgroup, bounded by the LDS staging
 };
+// position of (row family s, row component r, column component c, column function j) inside a row node's chunk
+template <int NF> __device__ inline int enr_pos(int sa, int r, int c, int j) { return ((sa * 3 + r) * 3 + c) * NF + j; }
 
 typedef double d4v __attribute__((ext_vector_type(4)));
 
@@ -73,7 +80,7 @@ __global__ __launch_bounds__(64 * EnrCfg<S>::NW) void k_enr_elem(const Slab s, c
   using Cf = EnrCfg<S>;
   constexpr int NF = Cf::NF, D = Cf::D, KE = Cf::KE, NW = Cf::NW, NE = S - 1;
   static_assert(!MFMA || S == 2, "the FP64 MFMA contraction is the 16-function tile of one enrichment family");
-  __shared__ __attribute__((aligned(16))) double sh_ke[NW][KE];
+  __shared__ __attribute__((aligned(16))) double sh_ke[NW][Cf::DIRECT ? 2 : KE];
   __shared__ double sh_T[NW][8][NF][3];
   __shared__ double sh_cf[NW][8][4];
   __shared__ double sh_x[NW][24];
@@ -161,9 +168,101 @@ __global__ __launch_bounds__(64 * EnrCfg<S>::NW) void k_enr_elem(const Slab s, c
   }
   wave_sync();
 
-  // ---- contraction: 3x3 block of every pair of scalar functions, into the staging area in scratch order ----
-  double *ke = sh_ke[w];
-  if constexpr (!MFMA) {
+  // ---- contraction: 3x3 block of every pair of scalar functions ----
+  const int slot = (int)(ez % a.nring);
+  double *kg = a.ke + ((slot * my + ey) * mx + ex) * (int64_t)KE;  // this element's matrix in the ring
+  constexpr int CH = 8 * D * D;                                     // doubles of a row node's chunk
+  if constexpr (Cf::DIRECT) {
+    // lane l: column function j = l & 15; row functions i = (l >> 4) + 4 g, g < 4 (the C/D map of v_mfma_f64_16x16x4)
+    const int j = lane & 15, ib = lane >> 4;
+    d4v acc[3][3];
+    if constexpr (MFMA) {
+      // A and B operands of lane l: function l & 15 at Gauss point (l >> 4) + 4 h of K-step h
+      double ag[2][3], b11[2][3], b12[2][3], b44[2][3];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int q = ib + 4 * h;
+        const double d11 = sh_cf[w][q][0], d12 = sh_cf[w][q][1], d44 = sh_cf[w][q][2];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const double g = sh_T[w][q][j][k];
+          ag[h][k] = g;
+          b11[h][k] = d11 * g;
+          b12[h][k] = d12 * g;
+          b44[h][k] = d44 * g;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          d4v v = {0.0, 0.0, 0.0, 0.0};
+          if (r != c) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              v = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[h][r], b12[h][c], v, 0, 0, 0);  // D12 g_i[r] g_j[c]
+              v = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[h][c], b44[h][r], v, 0, 0, 0);  // D44 g_i[c] g_j[r]
+            }
+          } else {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              v = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[h][r], b11[h][r], v, 0, 0, 0);
+#pragma unroll
+              for (int k = 0; k < 3; k++)
+                if (k != r) v = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[h][k], b44[h][k], v, 0, 0, 0);
+            }
+          }
+          acc[r][c] = v;
+        }
+    } else {
+      double av[4][9];
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+#pragma unroll
+        for (int q = 0; q < 9; q++) av[g][q] = 0.0;
+#pragma unroll 1
+      for (int q = 0; q < 8; q++) {
+        const double d11 = sh_cf[w][q][0], d12 = sh_cf[w][q][1], d44 = sh_cf[w][q][2];
+        const double *gjp = sh_T[w][q][j];
+        const double gj[3] = {gjp[0], gjp[1], gjp[2]};
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const double *ga = sh_T[w][q][ib + 4 * g];
+          double l[3], m[3], qq[3];
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            l[k] = d12 * ga[k];
+            m[k] = d44 * ga[k];
+            qq[k] = d11 * ga[k];
+          }
+          add_block<KIND_ELASTIC, 3>(av[g], l, m, qq, gj);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          d4v v = {av[0][3 * r + c], av[1][3 * r + c], av[2][3 * r + c], av[3][3 * r + c]};
+          acc[r][c] = v;
+        }
+    }
+    // register g of lane l: row function i = ib + 4 g = 8 s + a.  One store instruction = 4 whole 128-byte lines.
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const int i = ib + 4 * g, sa = i >> 3, na = i & 7;
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+#if FEMASM_EXP == 1  // profiling build: the contraction without its stores
+          asm volatile("" ::"v"(acc[r][c][g]));
+#else
+          kg[na * CH + enr_pos<NF>(sa, r, c, j)] = acc[r][c][g];
+#endif
+        }
+    }
+  } else {
+    double *ke = sh_ke[w];
     const int na = lane >> 3, nb = lane & 7;  // node pair (a, b)
 #pragma unroll 1
     for (int sa = 0; sa < S; sa++) {
@@ -195,65 +294,20 @@ __global__ __launch_bounds__(64 * EnrCfg<S>::NW) void k_enr_elem(const Slab s, c
 #pragma unroll
         for (int c = 0; c < 3; c++)
 #pragma unroll
-          for (int cc = 0; cc < 3; cc++) ke[((na * D + 3 * sa + c) * 8 + nb) * D + 3 * t + cc] = acc[t][3 * c + cc];
+          for (int cc = 0; cc < 3; cc++) ke[na * CH + enr_pos<NF>(sa, c, cc, 8 * t + nb)] = acc[t][3 * c + cc];
     }
-  } else {
-    // lane l: function fn = l & 15 (both operands), Gauss points p = (l >> 4) + 4 h of K-step h
-    const int fn = lane & 15, pq = lane >> 4;
-    double ag[2][3], b11[2][3], b12[2][3], b44[2][3];
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int q = pq + 4 * h;
-      const double d11 = sh_cf[w][q][0], d12 = sh_cf[w][q][1], d44 = sh_cf[w][q][2];
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        const double g = sh_T[w][q][fn][k];
-        ag[h][k] = g;
-        b11[h][k] = d11 * g;
-        b12[h][k] = d12 * g;
-        b44[h][k] = d44 * g;
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        d4v acc = {0.0, 0.0, 0.0, 0.0};
-        if (r != c) {
-#pragma unroll
-          for (int h = 0; h < 2; h++) {
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[h][r], b12[h][c], acc, 0, 0, 0);  // D12 g_i[r] g_j[c]
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[h][c], b44[h][r], acc, 0, 0, 0);  // D44 g_i[c] g_j[r]
-          }
-        } else {
-#pragma unroll
-          for (int h = 0; h < 2; h++) {
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[h][r], b11[h][r], acc, 0, 0, 0);
-#pragma unroll
-            for (int k = 0; k < 3; k++)
-              if (k != r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[h][k], b44[h][k], acc, 0, 0, 0);
-          }
-        }
-        // result register g of lane l: row function i = (l >> 4) + 4 g, column function j = l & 15
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-          const int i = pq + 4 * g, sa = i >> 3, na = i & 7, t = fn >> 3, nb = fn & 7;
-          ke[((na * D + 3 * sa + r) * 8 + nb) * D + 3 * t + c] = acc[g];
-        }
-      }
-  }
-  wave_sync();
-
-  // ---- staging -> scratch ring, 16 B per lane, whole lines (KE * 8 bytes is a multiple of 128) ----
-  const int slot = (int)(ez % a.nring);
-  double2 *dst = reinterpret_cast<double2 *>(a.ke + ((slot * my + ey) * mx + ex) * (int64_t)KE);
-  const double2 *src = reinterpret_cast<const double2 *>(ke);
+    wave_sync();
+    // staging -> scratch ring, 16 B per lane, whole lines (KE * 8 bytes is a multiple of 128)
+    double2 *dst = reinterpret_cast<double2 *>(kg);
+    const double2 *src = reinterpret_cast<const double2 *>(ke);
 #pragma unroll 2
-  for (int t = lane; t < KE / 2; t += 64) dst[t] = src[t];
+    for (int t = lane; t < KE / 2; t += 64) dst[t] = src[t];
+  }
 }
 
 // ---------------------------------------------------------------------------
-// Segmented reduction: one wave per node of node layers [s0, s1).  D is a runtime number here (3 ... 12).
+// Segmented reduction: one wave per node of node layers [s0, s1).  D = DMAX is a compile-time number (the index
+// arithmetic of the deposits is divisions by D and 8 S: with a runtime D they cost more than the memory traffic).
 // ---------------------------------------------------------------------------
 constexpr int ENR_GW = 4;  // waves per workgroup
 template <int DMAX>
@@ -261,7 +315,7 @@ __global__ __launch_bounds__(64 * ENR_GW) void k_enr_gather(const Slab s, const 
   __shared__ double sh_acc[ENR_GW][27 * DMAX * DMAX];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t M = s.dim[0], N = s.dim[1], P = s.dim[2];
-  const int D = s.dof;
+  constexpr int D = DMAX;
   const int64_t q = (int64_t)blockIdx.x * ENR_GW + w;
   if (q >= M * N * (a.s1 - a.s0)) return;
   const int64_t i = q % M, j = (q / M) % N, k = a.s0 + q / (M * N);
@@ -277,27 +331,60 @@ __global__ __launch_bounds__(64 * ENR_GW) void k_enr_gather(const Slab s, const 
   for (int t = lane; t < nvals; t += 64) acc[t] = 0.0;
   wave_sync();
   const bool dirichlet = (a.bc == BC_S3) && on_boundary(s, i, j, k);
+  constexpr int NF = 8 * (D / 3);
+  // chunk position t -> (row dof, neighbour, column dof) -> position in the node's CSR block
+  auto deposit = [&](int t, int ox, int oy, int oz, double v) {
+    const int sa = t / (9 * NF), rem = t - sa * 9 * NF, r = rem / (3 * NF), rem2 = rem - r * 3 * NF, c = rem2 / NF;
+    const int jf = rem2 - c * NF, tt = jf >> 3, b = jf & 7;
+    const int dx = ox + HDI[b], dy = oy + HDJ[b], dz = oz + HDK[b];
+    const int nbr = ((dz + 1 - zi0) * cnty + (dy + 1 - yi0)) * cntx + (dx + 1 - xi0);
+    const int pos = (3 * sa + r) * rowlen + nbr * D + 3 * tt + c;
+    acc[pos] = acc[pos] + v;
+  };
   if (!dirichlet) {
-#pragma unroll 1
-    for (int oz = -1; oz <= 0; oz++)
-#pragma unroll 1
-      for (int oy = -1; oy <= 0; oy++)
-#pragma unroll 1
-        for (int ox = -1; ox <= 0; ox++) {  // elements in the reference's loop order (S3:687-689)
-          const int64_t ex = i + ox, ey = j + oy, ez = k + oz;
-          if (ex < 0 || ex >= mx || ey < 0 || ey >= my || ez < s.els || ez >= s.ele) continue;
-          const int al = hex_idx(-ox, -oy, -oz);
-          const int slot = (int)(ez % a.nring);
-          const double *chunk = a.ke + (((slot * my + ey) * mx + ex) * (int64_t)8 + al) * KN;
-          for (int t = lane; t < KN; t += 64) {
-            const int qr = t / (8 * D), rem = t - qr * 8 * D, b = rem / D, r = rem - b * D;
-            const int dx = ox + HDI[b], dy = oy + HDJ[b], dz = oz + HDK[b];
-            const int nbr = ((dz + 1 - zi0) * cnty + (dy + 1 - yi0)) * cntx + (dx + 1 - xi0);
-            const int pos = qr * rowlen + nbr * D + r;
-            acc[pos] = acc[pos] + chunk[t];
-          }
-          wave_sync();  // the next element's read-modify-writes come after these
+    if constexpr (DMAX <= 6) {
+      // all eight chunks are requested before the first is added (memory-level parallelism: 18 KB per wave in flight),
+      // then added in the reference's element order (S3:687-689)
+      constexpr int NIT = (8 * DMAX * DMAX + 63) / 64;
+      double v[8][NIT];
+#pragma unroll
+      for (int q8 = 0; q8 < 8; q8++) {
+        const int ox = (q8 & 1) - 1, oy = ((q8 >> 1) & 1) - 1, oz = (q8 >> 2) - 1;
+        const int64_t ex = i + ox, ey = j + oy, ez = k + oz;
+        const bool ok = !(ex < 0 || ex >= mx || ey < 0 || ey >= my || ez < s.els || ez >= s.ele);
+        const int64_t exc = ok ? ex : 0, eyc = ok ? ey : 0, ezc = ok ? ez : s.els;
+        const int slot = (int)(ezc % a.nring);
+        const double *chunk = a.ke + (((slot * my + eyc) * mx + exc) * (int64_t)8 + hex_idx(-ox, -oy, -oz)) * KN;
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+          const int t = lane + 64 * it;
+          v[q8][it] = (ok && t < KN) ? chunk[t] : 0.0;
         }
+      }
+#pragma unroll
+      for (int q8 = 0; q8 < 8; q8++) {
+        const int ox = (q8 & 1) - 1, oy = ((q8 >> 1) & 1) - 1, oz = (q8 >> 2) - 1;
+        const int64_t ex = i + ox, ey = j + oy, ez = k + oz;
+        if (ex < 0 || ex >= mx || ey < 0 || ey >= my || ez < s.els || ez >= s.ele) continue;
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+          const int t = lane + 64 * it;
+          if (t < KN) deposit(t, ox, oy, oz, v[q8][it]);
+        }
+        wave_sync();  // the next element's read-modify-writes come after these
+      }
+    } else {
+#pragma unroll 1
+      for (int q8 = 0; q8 < 8; q8++) {
+        const int ox = (q8 & 1) - 1, oy = ((q8 >> 1) & 1) - 1, oz = (q8 >> 2) - 1;
+        const int64_t ex = i + ox, ey = j + oy, ez = k + oz;
+        if (ex < 0 || ex >= mx || ey < 0 || ey >= my || ez < s.els || ez >= s.ele) continue;
+        const int slot = (int)(ez % a.nring);
+        const double *chunk = a.ke + (((slot * my + ey) * mx + ex) * (int64_t)8 + hex_idx(-ox, -oy, -oz)) * KN;
+        for (int t = lane; t < KN; t += 64) deposit(t, ox, oy, oz, chunk[t]);
+        wave_sync();
+      }
+    }
   }
   // row rules: Dirichlet faces (all dofs of the node), blocked redundant dofs (enriched dofs of inactive families)
   const int self = (((k > 0) * cnty + (j > 0)) * cntx + (i > 0)) * D;
@@ -414,6 +501,105 @@ __global__ __launch_bounds__(128) void k_enr_rhs_elem(const Slab s, const EnrArg
   }
 #pragma unroll
   for (int t = 0; t < 8 * D; t++) a.elemF[ef_idx_rt(e, t, 8 * D)] = F[t];
+}
+
+// The same element vectors, 8 lanes per element and 8 elements per wave (the form the step uses; the thread-per-element
+// kernel above stays as the plain statement of the formulas and is what FEMASM_ENR_RHS_SIMPLE=1 selects).
+// Lane (x, j) of element x: face Gauss points j, j + 8, j + 16 (one per face pair) and volume Gauss point j -> traction
+// sigma.n x face Jacobian, w detJ f and the enrichment factors phi_s of those points into LDS; then lane j = node j
+// sums its D entries over the 24 + 8 points.  Same terms as the kernel above in another order (rounding only).
+template <int S>
+__global__ __launch_bounds__(256) void k_enr_rhs_elem8(const Slab s, const EnrArgs a, int64_t nel) {
+  constexpr int D = 3 * S, NE = S - 1, NW = 4;
+  __shared__ double sh_xc[NW][8][24];
+  __shared__ double sh_tr[NW][8][32][3];       // [point: 24 face, then 8 volume][component]
+  __shared__ double sh_phi[NW][8][NE > 0 ? NE : 1][32];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, x = lane >> 3, j = lane & 7;
+  const int64_t e0 = ((int64_t)blockIdx.x * NW + w) * 8;
+  if (e0 >= nel) return;
+  const bool live = e0 + x < nel;
+  const int64_t e = live ? e0 + x : nel - 1;  // idle lanes repeat the last element (clamped, never masked loads)
+  const int64_t M = s.dim[0], N = s.dim[1];
+  const int64_t mx = M - 1, my = N - 1;
+  const int64_t ex = e % mx, ey = (e / mx) % my, ez = s.els + e / (mx * my);
+  const double *rec = a.gp + (ex + mx * (ey + my * (ez - s.mat_e_ks))) * (int64_t)a.stride;
+  auto wave_sync = [&]() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  };
+  {
+    const int64_t node = (ex + HDI[j]) + M * ((ey + HDJ[j]) + N * (ez + HDK[j] - s.cks));
+#pragma unroll
+    for (int d = 0; d < 3; d++) sh_xc[w][x][3 * j + d] = a.coords[3 * node + d];
+  }
+  wave_sync();
+  const double *xc = sh_xc[w][x];
+  const double dx = fabs(xc[0] - xc[9]), dy = fabs(xc[1] - xc[4]), dz = fabs(xc[2] - xc[14]);  // S3:560-562
+  const double *gx = rec + 184, *gy = rec + 256, *gz = rec + 328, *EB = rec + 112, *nuB = rec + 136;
+#pragma unroll
+  for (int ax = 0; ax < 3; ax++) {
+    const int p = j + 8 * ax;
+    const double pe = EB[p], pn = nuB[p];
+    const double factor = pe * (1 - pn) / ((1.0 + pn) * (1.0 - 2.0 * pn));
+    const double d11 = factor * 1.0, d12 = factor * (pn / (1 - pn)), d44 = factor * (0.5 * (1 - 2 * pn) / (1 - pn));
+    const double e0_ = gx[3 * p], e1 = gy[3 * p + 1], e2 = gz[3 * p + 2];
+    const double e3 = gx[3 * p + 1] + gy[3 * p], e4 = gy[3 * p + 2] + gz[3 * p + 1], e5 = gx[3 * p + 2] + gz[3 * p];
+    const double z0 = d11 * e0_ + d12 * e1 + d12 * e2;
+    const double z1 = d12 * e0_ + d11 * e1 + d12 * e2;
+    const double z2 = d12 * e0_ + d12 * e1 + d11 * e2;
+    const double z3 = d44 * e3, z4 = d44 * e4, z5 = d44 * e5;
+    const double side = (j & 4) ? -1.0 : 1.0;  // points 0-3 of a face pair: +1 face, 4-7: -1 face
+    double sn[3], Jp;
+    if (ax == 0)      { sn[0] = z0 * side; sn[1] = z3 * side; sn[2] = z5 * side; Jp = (0.5 * dy) * (0.5 * dz); }
+    else if (ax == 1) { sn[0] = z3 * side; sn[1] = z1 * side; sn[2] = z4 * side; Jp = (0.5 * dx) * (0.5 * dz); }
+    else              { sn[0] = z5 * side; sn[1] = z4 * side; sn[2] = z2 * side; Jp = (0.5 * dx) * (0.5 * dy); }
+    const double fac = 1.0 * Jp;
+#pragma unroll
+    for (int c = 0; c < 3; c++) sh_tr[w][x][p][c] = fac * sn[c];
+#pragma unroll
+    for (int m = 0; m < NE; m++) {
+      const double *en = rec + a.base + 64 * m;
+      double v = en[40 + p];
+      if (a.sgfem)
+#pragma unroll
+        for (int b = 0; b < 8; b++) v = v - c_tab3.NF[p][b] * en[b];
+      sh_phi[w][x][m][p] = v;
+    }
+  }
+  {
+    const double fac = 1.0 * det3_only(c_tab3.G[j], xc);
+    sh_tr[w][x][24 + j][0] = fac * rec[160 + j];
+    sh_tr[w][x][24 + j][1] = fac * rec[168 + j];
+    sh_tr[w][x][24 + j][2] = fac * rec[176 + j];
+#pragma unroll
+    for (int m = 0; m < NE; m++) {
+      const double *en = rec + a.base + 64 * m;
+      double v = en[8 + j];
+      if (a.sgfem)
+#pragma unroll
+        for (int b = 0; b < 8; b++) v = v - c_tab3.N[j][b] * en[b];
+      sh_phi[w][x][m][24 + j] = v;
+    }
+  }
+  wave_sync();
+  const int nact = enr_active(rec, a.base, j, NE);
+  double F[D];
+#pragma unroll
+  for (int t = 0; t < D; t++) F[t] = 0.0;
+#pragma unroll 4
+  for (int p = 0; p < 32; p++) {
+    const double Nn = (p < 24) ? c_tab3.NF[p][j] : c_tab3.N[p - 24][j];
+    const double t0 = sh_tr[w][x][p][0], t1 = sh_tr[w][x][p][1], t2 = sh_tr[w][x][p][2];
+    F[0] += Nn * t0; F[1] += Nn * t1; F[2] += Nn * t2;
+#pragma unroll
+    for (int m = 0; m < NE; m++) {
+      const double val = (m < nact) ? Nn * sh_phi[w][x][m][p] : 0.0;
+      F[3 * (1 + m)] += val * t0; F[3 * (1 + m) + 1] += val * t1; F[3 * (1 + m) + 2] += val * t2;
+    }
+  }
+  if (live)
+#pragma unroll
+    for (int t = 0; t < D; t++) a.elemF[ef_idx_rt(e, j * D + t, 8 * D)] = F[t];
 }
 
 // one thread per (node, dof) of node layers [s0, s1): element contributions in k -> j -> i order, then the row rules

@@ -154,3 +154,42 @@ def props_e2(M, N, coords, e0=0, e1=None, ck0=0, E=1.0, nu=0.33):
         out[..., 8 + p] = E
         out[..., 12 + p] = nu
     return out.reshape(-1)
+
+
+def props_enriched(M, N, P, coords, n_enr=1, e0=0, e1=None, ck0=0, E=90.0, nu=0.28, base=408):
+    """Config 5 records for bench.py and the full-size tests: the R3 record (props_s3 + enrich_type = 1, n_enrich =
+    n_enr at every node) followed by 64 doubles per family: psi at the 8 nodes, at the 8 Gauss points, grad psi at
+    the Gauss points, psi at the 24 face points.  Families: smooth polynomials / trigonometric functions (the
+    reference has no enrichment functions of its own)."""
+    e1 = P - 1 if e1 is None else e1
+    stride = base + 64 * n_enr
+    dev = coords.device
+    s3 = props_s3(M, N, P, coords, e0=e0, e1=e1, ck0=ck0, E=E, nu=nu, stride=400).reshape(-1, 400)
+    nel = s3.shape[0]
+    out = torch.zeros((nel, stride), device=dev, dtype=torch.float64)
+    out[:, :400] = s3
+    itype = torch.int32 if base == 408 else torch.int64
+    flags = torch.ones((nel, 16), device=dev, dtype=itype)
+    flags[:, 8:] = n_enr
+    out[:, 400:base] = flags.view(torch.float64).reshape(nel, base - 400)
+    c4 = coords.reshape(-1, N, M, 3)[e0 - ck0:e1 - ck0 + 1]
+    xn = [_hex_node_coords(c4, n).reshape(-1, 3) for n in range(8)]
+    gp = s3[:, 0:24].reshape(nel, 8, 3)
+    gpb = s3[:, 24:96].reshape(nel, 24, 3)
+
+    def psi(m, x, y, z):
+        if m == 0:
+            return x * x + 0.5 * y * z + 0.25 * z, 2 * x, 0.5 * z, 0.5 * y + 0.25
+        if m == 1:
+            return torch.sin(2 * x) * y, 2 * torch.cos(2 * x) * y, torch.sin(2 * x), torch.zeros_like(x)
+        return z * z * x + y, z * z, torch.ones_like(x), 2 * z * x
+
+    for m in range(n_enr):
+        o = base + 64 * m
+        for a in range(8):
+            out[:, o + a] = psi(m, xn[a][:, 0], xn[a][:, 1], xn[a][:, 2])[0]
+        v = psi(m, gp[:, :, 0], gp[:, :, 1], gp[:, :, 2])
+        out[:, o + 8:o + 16] = v[0]
+        out[:, o + 16:o + 40] = torch.stack([v[1], v[2], v[3]], dim=-1).reshape(nel, 24)
+        out[:, o + 40:o + 64] = psi(m, gpb[:, :, 0], gpb[:, :, 1], gpb[:, :, 2])[0]
+    return out.reshape(-1)
