@@ -351,7 +351,7 @@ def main():
             achieved = None
         level = plan.fast_path()
         if wl == "enriched3d":
-            mode = args.enr_contraction if args.enr_contraction != "default" else ("mfma" if args.n_enr == 1 else "valu")
+            mode = args.enr_contraction if args.enr_contraction != "default" else "valu"
             kernel = f"k_enr_elem<S={1 + args.n_enr},{mode}> + k_enr_gather (all of K)"
         elif wl == "elastic2d":
             kernel = "k_assemble_e2_rect" if level == 2 else "k_assemble_rows<PLANE_STRAIN2D>"

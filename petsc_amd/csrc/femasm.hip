@@ -109,8 +109,10 @@ struct femasm_plan {
   int64_t elemF_count = 0;             // doubles allocated in elemF
   double *lines = nullptr;             // P3 RHS on a rectilinear mesh: the three 1-D factor lines
   // interface buffers (K rows of one node layer in CSR layout, then the b slice)
-  double *send = nullptr, *recv = nullptr;
-  int64_t send_count = 0, recv_count = 0, send_nnz = 0, recv_nnz = 0;
+  double *send = nullptr, *recv = nullptr;   // wire buffers: PACKED K rows (k_iface_pack) then the b slice
+  int64_t send_count = 0, recv_count = 0, send_nnz = 0, recv_nnz = 0;  // (counts of the packed form)
+  double *sfull = nullptr;                   // full CSR rows of node layer ks-1, as the stiffness kernels write them
+  int64_t sfull_nnz = 0;
   bool own_send = true, own_recv = true;
 
   unsigned long long *flags_host = nullptr;  // pinned: the flags' read-back is a real asynchronous copy, not a staged one
@@ -366,6 +368,14 @@ int launch_rect_check(femasm_plan *p) {
   return 0;
 }
 
+// full rows of node layer ks-1 (p->sfull) -> the packed wire buffer (p->send)
+int launch_iface_pack(femasm_plan *p) {
+  const int64_t plane = (p->s.nsd == 3) ? p->s.dim[0] * p->s.dim[1] : p->s.dim[0];
+  hipLaunchKernelGGL(k_iface_pack, dim3(nblk(plane, 4)), dim3(256), 0, p->stream, p->s, p->s.ks - 1, p->sfull, p->send);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 template <int KIND>
 int launch_rhs(femasm_plan *p, const femasm_material *mat, int bc, double *out, int64_t s0, int64_t s1, int iface,
                bool do_elem, const Slab *slab = nullptr, int64_t nel = -1) {
@@ -526,7 +536,10 @@ int assemble_enriched(femasm_plan *p, const femasm_material *mat, int bc, double
     a.ke = p->ke_ring;
     a.nring = (int)nring;
     const int64_t chunk = nring - 1;
-    const bool mfma = (S == 2) && (p->enr_mfma < 0 ? true : p->enr_mfma != 0);
+    // default: VALU.  Measured: both variants do the same 86 016 flops per element and FP64 MFMA has the
+    // VALU's peak on this part, so the contraction alone is a tie (0.385 vs 0.395 ms per 147 456 elements) and the
+    // kernel is bound by its stores either way (0.687 vs 0.657 ms)
+    const bool mfma = (S == 2) && p->enr_mfma == 1;
     auto gather = [&](double *out, int64_t l0, int64_t l1, int iface) {
       if (l1 <= l0) return;
       EnrArgs g = a;
@@ -557,8 +570,10 @@ int assemble_enriched(femasm_plan *p, const femasm_material *mat, int bc, double
         default: launch_enr_elem<4>(p, el, nelem, false); break;
       }
       HIPCHK(hipGetLastError());
-      if (L0 == s.els && s.ks > 0 && p->send)  // partial rows of node layer ks-1 (element layer els only), owed to the rank below
-        gather(p->send, s.ks - 1, s.ks, 1);
+      if (L0 == s.els && s.ks > 0 && p->send) {  // partial rows of node layer ks-1 (element layer els only), owed to the rank below
+        gather(p->sfull, s.ks - 1, s.ks, 1);
+        if (int rcp = launch_iface_pack(p)) return rcp;
+      }
       // node layers this chunk completes: k needs element layers k-1 and k (those this rank assembles)
       const int64_t n0 = (L0 == s.els) ? s.ks : L0, n1 = (L1 == s.ele) ? s.ke : L1;
       gather(csr_values, n0, n1, 0);
@@ -749,13 +764,16 @@ int femasm_plan_create(const femasm_mesh *mesh, const femasm_quad *quad, int dev
   PCHK(hipMalloc(&p->elemF, (size_t)p->elemF_count * sizeof(double)));
 
   // interface buffers: rows of node layer ks-1 (owed to the rank below) and of ke-1 (owed to us)
+  const int64_t packed_nnz = (int64_t)dof * dof * 2 * ((nsd == 3) ? tot1(N) * tot1(M) : tot1(M));
   if (s.ks > 0) {
-    p->send_nnz = layer_nnz(s, s.ks - 1, s.ks);
+    p->sfull_nnz = layer_nnz(s, s.ks - 1, s.ks);
+    PCHK(hipMalloc(&p->sfull, (size_t)p->sfull_nnz * sizeof(double)));
+    p->send_nnz = packed_nnz;
     p->send_count = p->send_nnz + plane * dof;
     PCHK(hipMalloc(&p->send, p->send_count * sizeof(double)));
   }
   if (s.ke < SL) {
-    p->recv_nnz = layer_nnz(s, s.ke - 1, s.ke);
+    p->recv_nnz = packed_nnz;
     p->recv_count = p->recv_nnz + plane * dof;
     PCHK(hipMalloc(&p->recv, p->recv_count * sizeof(double)));
   }
@@ -784,7 +802,7 @@ int femasm_plan_destroy(femasm_plan *p) {
   }
 #endif
   void *bufs[] = {p->coords_dev, p->rowptr, p->colidx, p->elemF, p->own_send ? p->send : nullptr,
-                  p->own_recv ? p->recv : nullptr, p->bad, p->stage_vals, p->stage_b, p->stage_gp, p->lines, p->partial, p->stage_u, p->ke_ring};
+                  p->own_recv ? p->recv : nullptr, p->bad, p->stage_vals, p->stage_b, p->stage_gp, p->lines, p->partial, p->stage_u, p->ke_ring, p->sfull};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   if (p->flags_host) (void)hipHostFree(p->flags_host);
@@ -942,10 +960,11 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
     if (r) return r;
     if (s.ks > 0 && !iface_done) {  // partial rows of node layer ks-1, owed to the rank below
       switch (p->kind) {
-        case KIND_POISSON: r = launch_K<KIND_POISSON>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1); break;
-        case KIND_PLANE:   r = launch_K<KIND_PLANE>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1); break;
-        case KIND_ELASTIC: r = launch_K<KIND_ELASTIC>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1); break;
+        case KIND_POISSON: r = launch_K<KIND_POISSON>(p, &mloc, bc, p->sfull, s.ks - 1, s.ks, 1); break;
+        case KIND_PLANE:   r = launch_K<KIND_PLANE>(p, &mloc, bc, p->sfull, s.ks - 1, s.ks, 1); break;
+        case KIND_ELASTIC: r = launch_K<KIND_ELASTIC>(p, &mloc, bc, p->sfull, s.ks - 1, s.ks, 1); break;
       }
+      if (!r) r = launch_iface_pack(p);
     }
     return r;
   };
@@ -1101,9 +1120,9 @@ int femasm_assemble_interface(femasm_plan *p, const femasm_material *mat, const 
   int rc = 0;
   auto layer_K = [&]() -> int {
     switch (p->kind) {
-      case KIND_POISSON: return launch_K<KIND_POISSON>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1);
-      case KIND_PLANE:   return launch_K<KIND_PLANE>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1);
-      default:           return launch_K<KIND_ELASTIC>(p, &mloc, bc, p->send, s.ks - 1, s.ks, 1);
+      case KIND_POISSON: return launch_K<KIND_POISSON>(p, &mloc, bc, p->sfull, s.ks - 1, s.ks, 1);
+      case KIND_PLANE:   return launch_K<KIND_PLANE>(p, &mloc, bc, p->sfull, s.ks - 1, s.ks, 1);
+      default:           return launch_K<KIND_ELASTIC>(p, &mloc, bc, p->sfull, s.ks - 1, s.ks, 1);
     }
   };
   p->used_fast = false;
@@ -1128,6 +1147,8 @@ int femasm_assemble_interface(femasm_plan *p, const femasm_material *mat, const 
     p->used_fast = false;
     if (rc) return rc;
   }
+  rc = launch_iface_pack(p);  // (behind the conditional general kernels: the rows are final here)
+  if (rc) return rc;
   // element vectors of the one element layer that touches node layer ks-1 from above (it is the first layer
   // of the plan's element-vector array, where the full call will write the same numbers again)
   Slab sl = s;

@@ -1429,9 +1429,37 @@ __global__ __launch_bounds__(256) void k_poisson_rhs_rect(const Slab s, const RA
 }
 
 // ---------------------------------------------------------------------------
-// interface apply: own + received on the top owned node layer; one wave per node (its dof rows are one
-// contiguous range of the CSR array, read and written coalesced), Dirichlet nodes skipped
+// Slab interface.  The rows of node layer L = ks-1 that a rank owes to the rank below come from ONE element layer
+// (L), so only the columns in node layers L and L+1 can be non-zero: 18 dof of an interior row's 27 dof.  The wire
+// buffer holds those two thirds only ("packed": per node, dof rows of 2 * cnt_rest * dof values; SURVEY section 5:
+// 21.6 MB instead of 32 MB at 128^3 S3), then the b slice.
+//   k_iface_pack   full CSR rows of the layer (what the stiffness kernels write) -> packed
+//   k_iface_apply  own + received on the top owned node layer (the same layer seen from below), Dirichlet nodes skipped
+// One wave per node; a node's rows are contiguous in both forms.
 // ---------------------------------------------------------------------------
+__device__ inline int64_t iface_inplane_pairs(const Slab &s, int64_t i, int64_t j) {
+  return (s.nsd == 3) ? pre1(j, s.dim[1]) * tot1(s.dim[0]) + (int64_t)span1(j, s.dim[1]) * pre1(i, s.dim[0])
+                      : pre1(i, s.dim[0]);
+}
+__global__ __launch_bounds__(256) void k_iface_pack(const Slab s, int64_t layer, const double *full, double *packed) {
+  const int64_t M = s.dim[0], N = s.dim[1];
+  const int64_t nnode = (s.nsd == 3) ? M * N : M;
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (q >= nnode) return;
+  int64_t i = q % M, j, k;
+  if (s.nsd == 3) { j = q / M; k = layer; } else { j = layer; k = 0; }
+  const int crest = (s.nsd == 3) ? span1(i, M) * span1(j, N) : span1(i, M);
+  const int cs = span1(layer, (s.nsd == 3) ? s.dim[2] : N);
+  const int rl = cs * crest * s.dof, prl = 2 * crest * s.dof, skip = (layer > 0) ? crest * s.dof : 0;
+  const int64_t i0 = 0, j0 = (s.nsd == 3) ? 0 : layer, k0 = (s.nsd == 3) ? layer : 0;
+  const double *src = full + (row_start(s, i, j, k, 0) - row_start(s, i0, j0, k0, 0));
+  double *dst = packed + (int64_t)s.dof * s.dof * 2 * iface_inplane_pairs(s, i, j);
+  for (int t = lane; t < s.dof * prl; t += 64) {
+    const int c = t / prl, r = t - c * prl;
+    dst[t] = src[c * rl + skip + r];
+  }
+}
 __global__ __launch_bounds__(256) void k_iface_apply(const Slab s, int bc, double *vals, double *b,
                                                      const double *recvK, const double *recvB) {
   const int64_t M = s.dim[0], N = s.dim[1];
@@ -1443,12 +1471,17 @@ __global__ __launch_bounds__(256) void k_iface_apply(const Slab s, int bc, doubl
   int64_t i = q % M, j, k;
   if (s.nsd == 3) { j = q / M; k = layer; } else { j = layer; k = 0; }
   if (bc != BC_POISSON && is_bc_node(s, bc, i, j, k)) return;
-  const int64_t cnt = (int64_t)span1(i, s.dim[0]) * span1(j, s.dim[1]) * span1(k, s.dim[2]) * s.dof * s.dof;
-  const int64_t rs = row_start(s, i, j, k, 0);
-  const int64_t i0 = 0, j0 = (s.nsd == 3) ? 0 : layer, k0 = (s.nsd == 3) ? layer : 0;
-  const int64_t rs_recv = rs - row_start(s, i0, j0, k0, 0);
-  if (vals && recvK)
-    for (int64_t t = lane; t < cnt; t += 64) vals[rs + t] = vals[rs + t] + recvK[rs_recv + t];
+  const int crest = (s.nsd == 3) ? span1(i, M) * span1(j, N) : span1(i, M);
+  const int cs = span1(layer, (s.nsd == 3) ? s.dim[2] : N);
+  const int rl = cs * crest * s.dof, prl = 2 * crest * s.dof, skip = (layer > 0) ? crest * s.dof : 0;
+  if (vals && recvK) {
+    double *own = vals + row_start(s, i, j, k, 0);
+    const double *rcv = recvK + (int64_t)s.dof * s.dof * 2 * iface_inplane_pairs(s, i, j);
+    for (int t = lane; t < s.dof * prl; t += 64) {
+      const int c = t / prl, r = t - c * prl;
+      own[c * rl + skip + r] = own[c * rl + skip + r] + rcv[t];
+    }
+  }
   if (b && recvB && lane < s.dof) {
     const int64_t lr = (q + nnode * (layer - s.ks)) * s.dof + lane;
     b[lr] = b[lr] + recvB[q * s.dof + lane];

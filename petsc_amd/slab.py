@@ -52,12 +52,49 @@ def layer_nnz(nsd, dof, M, N, P, l0, l1):
 
 
 def interface_counts(nsd, dof, M, N, P, ks, ke):
-    """(send_count, recv_count) in doubles: CSR rows of one node layer + its b slice."""
+    """(send_count, recv_count) in doubles: the PACKED rows of one node layer + its b slice.  The rows a rank owes
+    come from one element layer, so only the columns in that node layer and the one above can be non-zero: two of
+    the three z-thirds (18 dof of 27 dof per interior row) are on the wire."""
     SL = P if nsd == 3 else N
     plane = M * N if nsd == 3 else M
-    send = layer_nnz(nsd, dof, M, N, P, ks - 1, ks) + plane * dof if ks > 0 else 0
-    recv = layer_nnz(nsd, dof, M, N, P, ke - 1, ke) + plane * dof if ke < SL else 0
+    packed = dof * dof * 2 * (_tot(N) * _tot(M) if nsd == 3 else _tot(M))
+    send = packed + plane * dof if ks > 0 else 0
+    recv = packed + plane * dof if ke < SL else 0
     return send, recv
+
+
+def _layer_nodes(nsd, dof, M, N, P, layer):
+    """(offset in the full CSR rows of the layer, offset in the packed form, rl, prl, skip) of every node of a layer"""
+    SL = P if nsd == 3 else N
+    cs = _span(layer, SL)
+    out, fo, po = [], 0, 0
+    for j in range(N if nsd == 3 else 1):
+        for i in range(M):
+            crest = _span(i, M) * (_span(j, N) if nsd == 3 else 1)
+            rl, prl, skip = cs * crest * dof, 2 * crest * dof, (crest * dof if layer > 0 else 0)
+            out.append((fo, po, rl, prl, skip))
+            fo += dof * rl
+            po += dof * prl
+    return out
+
+
+def pack_layer_rows(nsd, dof, M, N, P, layer, full):
+    """Host statement of k_iface_pack: the full CSR rows of node layer `layer` (numpy) -> the packed wire form (the
+    columns in node layers `layer` and `layer`+1 only)."""
+    import numpy as np
+    nodes = _layer_nodes(nsd, dof, M, N, P, layer)
+    out = np.empty(sum(dof * n[3] for n in nodes), dtype=full.dtype)
+    for fo, po, rl, prl, skip in nodes:
+        for c in range(dof):
+            out[po + c * prl:po + (c + 1) * prl] = full[fo + c * rl + skip:fo + c * rl + skip + prl]
+    return out
+
+
+def add_packed_rows(nsd, dof, M, N, P, layer, own_full, packed):
+    """Host statement of the K part of k_iface_apply (without its Dirichlet-node rule): own_full += received."""
+    for fo, po, rl, prl, skip in _layer_nodes(nsd, dof, M, N, P, layer):
+        for c in range(dof):
+            own_full[fo + c * rl + skip:fo + c * rl + skip + prl] += packed[po + c * prl:po + (c + 1) * prl]
 
 
 def exchange_interface(send, recv, rank, world):

@@ -40,7 +40,12 @@ def _worker(rank, world, port, kind, dims, q):
         send = recv = None
         if ks > 0:
             r0, r1 = plane * (ks - 1), plane * ks
-            send = torch.from_numpy(np.concatenate([K[rp[r0]:rp[r1]], b[r0:r1]]))
+            full = K[rp[r0]:rp[r1]]
+            packed = slab.pack_layer_rows(nsd, dof, M, N, P, ks - 1, full)
+            chk = np.zeros_like(full)      # nothing but zeros is left behind: the packed form loses no value
+            slab.add_packed_rows(nsd, dof, M, N, P, ks - 1, chk, packed)
+            assert np.array_equal(chk, full)
+            send = torch.from_numpy(np.concatenate([packed, b[r0:r1]]))
             assert send.numel() == sc
         if ke < P:
             recv = torch.empty(rc, dtype=torch.float64)
@@ -53,8 +58,9 @@ def _worker(rank, world, port, kind, dims, q):
         Kl, bl = K[rp[lo]:rp[hi]].copy(), b[lo:hi].copy()
         if recv is not None:
             t0, t1 = plane * (ke - 1), plane * ke
-            nk = rp[t1] - rp[t0]
-            Kl[rp[t0] - rp[lo]:] += recv[:nk].numpy()
+            nk = rc - plane
+            top = Kl[rp[t0] - rp[lo]:]     # (a view: added to in place)
+            slab.add_packed_rows(nsd, dof, M, N, P, ke - 1, top, recv[:nk].numpy())
             bl[t0 - lo:] += recv[nk:].numpy()
         q.put((rank, ks, ke, Kl, bl))
     finally:
