@@ -159,9 +159,12 @@ int femasm_assemble_system(femasm_plan *plan, const femasm_material *material, c
 
 /* Multi-GPU slab interface: what MatAssemblyEnd's stash exchange and
  * DMLocalToGlobal(ADD_VALUES) move in the reference (P3:345-346, 638-639; S3:710-711,
- * 794-795).  send_*: partial rows of node layer ks-1 (CSR layout of those rows, then the
- * b slice), owed to rank-1.  recv_*: same shape for node layer ke-1, filled by the caller
- * from rank+1 (RCCL/MPI).  Counts are in doubles; 0 where there is no neighbour. */
+ * 794-795).  send_*: partial rows of node layer ks-1, owed to rank-1, in PACKED form -- they
+ * come from one element layer, so only the columns in node layers ks-1 and ks can be non-zero:
+ * per node, dof rows of those two z-thirds (18 dof of an interior row's 27 dof) -- then the
+ * b slice.  recv_*: same shape for node layer ke-1, filled by the caller from rank+1
+ * (femasm_interface_exchange, or the caller's own RCCL/MPI).  Counts are in doubles; 0 where
+ * there is no neighbour. */
 int femasm_interface_buffers(femasm_plan *plan, double **send_buf, int64_t *send_count,
                              double **recv_buf, int64_t *recv_count);
 /* Use caller-owned DEVICE buffers (e.g. torch / PETSc device vectors registered with RCCL)
@@ -175,6 +178,14 @@ int femasm_interface_set_buffers(femasm_plan *plan, double *send_buf, double *re
  * errors (det J <= 0) are reported by the femasm_assemble_system call that must follow on the same inputs.
  * No counterpart in the reference (MatAssemblyBegin/End P3:345-346 is the closest). */
 int femasm_assemble_interface(femasm_plan *plan, const femasm_material *material, const femasm_bc *bc);
+/* The exchange itself, for C/C++ MPI drivers (one rank per GPU): replaces what MatAssemblyBegin/End's stash and
+ * DMLocalToGlobalBegin/End(ADD_VALUES) move (P3:345-346, 638-639; S3:710-711, 794-795).  comm is the caller's
+ * ncclComm_t (RCCL; created with ncclCommInitRank from an id the driver broadcasts over MPI); one ncclSend of the send
+ * buffer to rank_below and one ncclRecv of the receive buffer from rank_above, grouped, on the plan's stream -- after
+ * femasm_assemble_interface (overlapped with the rest of the assembly) or after femasm_assemble_system.  Pass -1 where
+ * there is no neighbour.  Returns without waiting; femasm_interface_apply, queued on the same stream, follows it.
+ * RCCL is looked up at run time (already loaded by the driver, or librccl.so): the library does not link against it. */
+int femasm_interface_exchange(femasm_plan *plan, void *comm, int rank_below, int rank_above);
 /* own + received, fixed order (deterministic); Dirichlet rows are left untouched. */
 int femasm_interface_apply(femasm_plan *plan, const femasm_bc *bc, double *csr_values, double *b);
 

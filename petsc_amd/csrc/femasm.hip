@@ -10,6 +10,8 @@
 #include "femasm_enriched.h"
 
 #include <hipcub/hipcub.hpp>
+#include <rccl/rccl.h>  // types and enums only: the four entry points used are resolved at run time (no link dependency)
+#include <dlfcn.h>
 
 #include <chrono>
 #include <cmath>
@@ -86,6 +88,41 @@ int static_scratch_for(int device, double **out) {
   }
   if (out) *out = g_scratch_ptr[device];
   return FEMASM_OK;
+}
+}  // namespace
+
+namespace {
+// RCCL entry points of femasm_interface_exchange, looked up once: first among the libraries already in the process (an MPI
+// driver linked against librccl, or torch's bundled copy), then by loading librccl.so
+struct RcclApi {
+  decltype(&ncclSend) send = nullptr;
+  decltype(&ncclRecv) recv = nullptr;
+  decltype(&ncclGroupStart) group_start = nullptr;
+  decltype(&ncclGroupEnd) group_end = nullptr;
+  decltype(&ncclGetErrorString) err = nullptr;
+  bool ok = false;
+};
+const RcclApi &rccl_api() {
+  static const RcclApi api = [] {
+    RcclApi a;
+    void *h = RTLD_DEFAULT;  // (a null handle: "every library already in the process")
+    bool have = dlsym(h, "ncclSend") != nullptr;
+    if (!have) {
+      h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+      if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+      have = h != nullptr;
+    }
+    if (have) {
+      a.send = (decltype(a.send))dlsym(h, "ncclSend");
+      a.recv = (decltype(a.recv))dlsym(h, "ncclRecv");
+      a.group_start = (decltype(a.group_start))dlsym(h, "ncclGroupStart");
+      a.group_end = (decltype(a.group_end))dlsym(h, "ncclGroupEnd");
+      a.err = (decltype(a.err))dlsym(h, "ncclGetErrorString");
+      a.ok = a.send && a.recv && a.group_start && a.group_end;
+    }
+    return a;
+  }();
+  return api;
 }
 }  // namespace
 
@@ -1365,6 +1402,26 @@ int femasm_interface_set_buffers(femasm_plan *p, double *send_buf, double *recv_
     p->recv = recv_buf;
     p->own_recv = false;
   }
+  return FEMASM_OK;
+}
+
+int femasm_interface_exchange(femasm_plan *p, void *comm, int rank_below, int rank_above) {
+  if (!p) return fail(FEMASM_ERR_ARG, "null plan");
+  if (!comm) return fail(FEMASM_ERR_ARG, "null communicator (an ncclComm_t is expected)");
+  const bool do_send = p->send_count > 0 && rank_below >= 0, do_recv = p->recv_count > 0 && rank_above >= 0;
+  if (!do_send && !do_recv) return FEMASM_OK;
+  const RcclApi &api = rccl_api();
+  if (!api.ok) return fail(FEMASM_ERR_HIP, "RCCL (librccl.so: ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd) was not found");
+  HIPCHK(hipSetDevice(p->device));
+  ncclComm_t c = (ncclComm_t)comm;
+  ncclResult_t r = api.group_start();
+  // one message per interface (S3:710-711 + 794-795: the stash of MatAssemblyEnd and DMLocalToGlobal's ghost sums):
+  // the packed K rows and the b slice of node layer ks-1 to the rank below, the same of layer ke-1 from the rank above
+  if (r == ncclSuccess && do_send) r = api.send(p->send, (size_t)p->send_count, ncclDouble, rank_below, c, p->stream);
+  if (r == ncclSuccess && do_recv) r = api.recv(p->recv, (size_t)p->recv_count, ncclDouble, rank_above, c, p->stream);
+  const ncclResult_t r2 = api.group_end();
+  if (r == ncclSuccess) r = r2;
+  if (r != ncclSuccess) return fail(FEMASM_ERR_HIP, "femasm_interface_exchange: RCCL: %s", api.err ? api.err(r) : "error");
   return FEMASM_OK;
 }
 

@@ -202,6 +202,22 @@ def test_compiled_driver_on_the_c_abi_converges_at_second_order(kind):
     assert r.stdout.count("L2 error ratio") == 2
 
 
+@pytest.mark.parametrize("kind,nel", [("poisson3d", 21), ("elastic3d", 14)])
+def test_compiled_slab_driver_exchanges_over_rccl(kind, nel):
+    """examples/femasm_slab_driver.cpp: two slabs on this GPU, femasm_assemble_interface -> femasm_interface_exchange
+    (RCCL send / receive of the packed interface rows, a one-rank communicator) -> femasm_assemble_system ->
+    femasm_interface_apply, from C++ on the C ABI alone; exit code 0 = the slabs equal the one-plan system to 1e-13."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "femasm_slab_driver")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe, kind, str(nel)], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "2 slabs over RCCL" in r.stdout
+
+
 def test_build_then_smoke_in_one_process():
     """__graft_entry__.build() loads libfemasm.so, smoke() then uses torch: the library and torch must end up on
     one HIP runtime whatever the order (regression: the library loaded first saw no device)."""
