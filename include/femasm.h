@@ -256,8 +256,16 @@ int femasm_coo_indices(femasm_plan *plan, int32_t index_bytes, void *coo_i, void
 int femasm_coord_moments(femasm_plan *plan, double mom[10]);
 int femasm_rigid_body_modes(femasm_plan *plan, const double mom[10], double *modes);
 
-/* Block until everything queued on the plan's stream has finished. */
+/* Block until everything queued on the plan's stream has finished; in asynchronous mode also the place where the
+ * errors of the calls before it are reported (FEMASM_ERR_GEOMETRY ...). */
 int femasm_plan_sync(femasm_plan *plan);
+
+/* No counterpart in the reference.  on != 0: femasm_assemble_system (device pointers, stats == NULL; P3 / E2 / S3 kinds)
+ * and femasm_interface_apply queue their kernels and return without waiting for the device, so that a driver can post
+ * the exchange, start the next slab or set up its solver meanwhile.  The results are final in stream order whatever the
+ * mesh: where a verified fast kernel is used, the general kernels are queued behind it and run on the device only if
+ * its premise failed.  Geometry errors of such a call are returned by femasm_plan_sync or by the next call on the plan. */
+int femasm_plan_set_async(femasm_plan *plan, int on);
 
 const char *femasm_last_error(void);
 const char *femasm_version(void);

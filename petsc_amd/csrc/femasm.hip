@@ -179,6 +179,10 @@ struct femasm_plan {
   int64_t stage_u_count = 0;
   double *static_scratch = nullptr;    // this device's copy of the file-scope `scratch` array (femasm_error_integrals_static)
 
+  bool async = false;                  // femasm_plan_set_async: assemble_system / interface_apply do not wait for the device
+  bool pending = false;                // an asynchronous call has not had its flags read yet (femasm_plan_sync does it)
+  bool pending_fast = false;           // ... and it used a fast kernel (premise flag bad[1] decides the plan's level)
+
   // config 5 (KIND_ENRICHED)
   int n_enr = 0;                       // enrichment families per node: dof = 3 (1 + n_enr)
   int enr_mfma = -1;                   // contraction of k_enr_elem: 0 VALU, 1 FP64 MFMA (n_enr == 1 only), -1 default
@@ -188,6 +192,24 @@ struct femasm_plan {
 };
 
 namespace {
+
+// Read the flags an asynchronous femasm_assemble_system left behind (waits for the stream): geometry errors and the
+// verdict of the fast kernels' premise -- K itself is already final in stream order (the general kernels were queued
+// behind the fast ones and ran on the device if the premise failed), only the plan's level is updated here.
+int finish_pending(femasm_plan *p) {
+  if (!p->pending) return FEMASM_OK;
+  p->pending = false;
+  unsigned long long *flags = p->flags_host;
+  flags[0] = flags[1] = flags[2] = 0;
+  HIPCHK(hipMemcpyAsync(flags, p->bad, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, p->stream));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  if (p->pending_fast && flags[1]) p->fast_level = 0;
+  p->pending_fast = false;
+  if (flags[2]) return fail(FEMASM_ERR_HIP, "internal: %llu wave hand-shakes of the row-sweep kernel timed out", flags[2]);
+  if (flags[0]) return fail(FEMASM_ERR_GEOMETRY, "%llu Gauss points with non-positive or NaN det(J) (reported by the "
+                            "asynchronous assembly before this call)", flags[0]);
+  return FEMASM_OK;
+}
 
 int traits_of(int kind, int &nsd, int &dof, int &nen, int &ngp, int &nfe, int n_enr = 0) {
   switch (kind) {
@@ -862,7 +884,16 @@ int femasm_plan_set_stream(femasm_plan *p, void *stream) {
 int femasm_plan_sync(femasm_plan *p) {
   if (!p) return fail(FEMASM_ERR_ARG, "null plan");
   HIPCHK(hipSetDevice(p->device));
+  if (p->pending) return finish_pending(p);
   HIPCHK(hipStreamSynchronize(p->stream));
+  return FEMASM_OK;
+}
+
+int femasm_plan_set_async(femasm_plan *p, int on) {
+  if (!p) return fail(FEMASM_ERR_ARG, "null plan");
+  HIPCHK(hipSetDevice(p->device));
+  if (int rc = finish_pending(p)) return rc;
+  p->async = on != 0;
   return FEMASM_OK;
 }
 
@@ -909,6 +940,7 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
   const bool iface_done = p->iface_done;  // consumed by this call, however it ends
   p->iface_done = false;
   HIPCHK(hipSetDevice(p->device));
+  if (int rcp = finish_pending(p)) return rcp;  // flags of an asynchronous call before this one: its errors surface here
   const auto t_begin = std::chrono::steady_clock::now();
   const int bc = bcs ? bcs->kind : FEMASM_BC_NONE;
   const Slab &s = p->s;
@@ -1033,6 +1065,24 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
   }
   if (stats) HIPCHK(hipEventRecord(p->ev[2], p->stream));
 
+  if (p->async && !stats && !vals_host && !b_host && !(p->gp_cur && p->gp_cur == p->stage_gp)) {
+    // asynchronous form: nothing is read back here.  K has to be final in stream order whatever the mesh, so the general
+    // kernels are queued behind the fast ones on the same rows and run only if the premise flag came up on the device
+    // (the scheme of femasm_assemble_interface); flags and the plan's level are dealt with by femasm_plan_sync or the next call.
+    if (d_vals && p->used_fast) {
+      const int level = p->fast_level;
+      p->fast_level = 0;
+      p->cond_general = true;
+      p->time_main = false;
+      rc = run_K();
+      p->cond_general = false;
+      p->fast_level = level;
+      if (rc) return rc;
+      p->pending_fast = true;
+    }
+    p->pending = true;
+    return FEMASM_OK;
+  }
   t0 = std::chrono::steady_clock::now();
   if (vals_host) HIPCHK(hipMemcpyAsync(csr_values, d_vals, p->nnz * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   if (b_host) HIPCHK(hipMemcpyAsync(b, d_b, p->nrows * sizeof(double), hipMemcpyDeviceToHost, p->stream));
@@ -1125,6 +1175,8 @@ int femasm_assemble_interface(femasm_plan *p, const femasm_material *mat, const 
   if (!p) return fail(FEMASM_ERR_ARG, "null plan");
   if (p->kind == KIND_ENRICHED)
     return fail(FEMASM_ERR_ARG, "the enriched kind has no split call: femasm_assemble_system fills the send buffer");
+  HIPCHK(hipSetDevice(p->device));
+  if (int rcp = finish_pending(p)) return rcp;
   HIPCHK(hipSetDevice(p->device));
   const int bc = bcs ? bcs->kind : FEMASM_BC_NONE;
   if (bc < 0 || bc > 3) return fail(FEMASM_ERR_ARG, "unknown bc kind %d", bc);
@@ -1436,7 +1488,7 @@ int femasm_interface_apply(femasm_plan *p, const femasm_bc *bcs, double *csr_val
   hipLaunchKernelGGL(k_iface_apply, dim3(nblk(plane, 4)), dim3(256), 0, p->stream, p->s, bc, csr_values, b,
                      p->recv, p->recv + p->recv_nnz);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(p->stream));
+  if (!p->async) HIPCHK(hipStreamSynchronize(p->stream));
   return FEMASM_OK;
 }
 

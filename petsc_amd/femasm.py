@@ -33,7 +33,7 @@ EXPORTS = [
     "femasm_interface_set_buffers", "femasm_interface_apply", "femasm_compress_bc_rows", "femasm_plan_sync", "femasm_last_error",
     "femasm_version", "femasm_plan_set_fast_path", "femasm_plan_get_fast_path", "femasm_assemble_interface", "femasm_error_integrals", "femasm_fill_properties", "femasm_apply_operator",
     "femasm_coo_indices", "femasm_coord_moments", "femasm_rigid_body_modes", "femasm_zero_rows",
-    "femasm_error_integrals_static", "femasm_plan_set_enriched_contraction", "femasm_interface_exchange",
+    "femasm_error_integrals_static", "femasm_plan_set_enriched_contraction", "femasm_interface_exchange", "femasm_plan_set_async",
 ]
 
 
@@ -168,6 +168,9 @@ class Plan:
         lv = C.c_int()
         _check(load().femasm_plan_get_fast_path(self._h, C.byref(lv)))
         return lv.value
+
+    def set_async(self, on=True):
+        _check(load().femasm_plan_set_async(self._h, C.c_int(1 if on else 0)))
 
     def sync(self):
         _check(load().femasm_plan_sync(self._h))

@@ -307,6 +307,43 @@ def test_host_material_then_device_material_on_one_plan(env):
     plan.close(); plan0.close()
 
 
+@pytest.mark.parametrize("kind,dims", [("p3", (20, 9, 11)), ("e2", (70, 19)), ("s3", (21, 7, 18))])
+@pytest.mark.parametrize("perturb", [False, True])
+def test_asynchronous_assembly_is_final_in_stream_order(env, kind, dims, perturb):
+    """femasm_plan_set_async: no host wait inside femasm_assemble_system; on a mesh that breaks the fast kernels'
+    premise the general kernels queued behind them must have produced the result by the time the stream gets there,
+    and the plan's level drops when the flags are read (femasm_plan_sync)."""
+    torch, F, dev = env["torch"], env["F"], env["dev"]
+    case = make_case(env, kind, dims, perturb=perturb)
+    M, N, P = case["dims"]
+    plan = F.Plan(case["problem"], M, N, P, coords=torch.from_numpy(case["coords"]).to(dev))
+    plan.set_async(True)
+    vals = torch.full((plan.nnz,), float("nan"), dtype=torch.float64, device=dev)
+    b = torch.full((plan.nrows,), float("nan"), dtype=torch.float64, device=dev)
+    mat = None if case["props"] is None else torch.from_numpy(case["props"]).to(dev)
+    for _ in range(2):   # the second call starts by reading the first one's flags
+        plan.assemble_system(vals, b, material=mat, stride=case["stride"], bc=case["bc"])
+    plan.sync()
+    assert plan.fast_path() == (0 if perturb else 2)
+    assert rel(vals.cpu().numpy(), case["K"]) <= TOL and rel(b.cpu().numpy(), case["b"]) <= TOL
+    plan.close()
+
+
+def test_asynchronous_assembly_reports_geometry_errors_at_sync(env):
+    torch, F, dev, O = env["torch"], env["F"], env["dev"], env["O"]
+    M = 5
+    coords = O.uniform_coords(3, M, M, M).reshape(-1, 3)
+    coords[2 + M * (2 + M * 2)] = coords[3 + M * (3 + M * 3)] + 0.3   # a node far outside its cell: inverted elements
+    plan = F.Plan(F.POISSON3D_Q1, M, M, M, coords=torch.from_numpy(coords.reshape(-1)).to(dev))
+    plan.set_async(True)
+    vals = torch.empty(plan.nnz, dtype=torch.float64, device=dev)
+    plan.assemble_system(vals, None, bc=F.BC_POISSON_INLOOP)      # returns at once, no error yet
+    with pytest.raises(F.FemasmError) as ei:
+        plan.sync()
+    assert ei.value.code == 3
+    plan.close()
+
+
 def test_compress_bc_rows_rejects_the_poisson_kind(env):
     """P3 never calls MatZeroRows: its boundary diagonal is the element valence, which the compressed form (diag 1)
     would misstate."""
