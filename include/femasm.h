@@ -87,7 +87,15 @@ enum {
   FEMASM_BC_E2_COMPRESSION = 2,  /* E2:877-887: i=M-1: ux=-1,uy=0 ; i=0: ux=+1,uy=0    */
   FEMASM_BC_S3_ALLFACES_EXACT = 3 /* S3:1912-1941: 6 faces x 3 dofs, exact displacement */
 };
-typedef struct { int32_t kind; int32_t reserved; } femasm_bc;
+typedef struct {
+  int32_t kind;
+  int32_t symmetric;  /* 0 (default): what the reference does, rows only.  1: OPT-IN symmetric elimination, NOT reference
+                         parity: after the rows-only system is complete every stored column c that is a Dirichlet dof
+                         is eliminated from the other rows with right-hand-side lifting, b[r] -= K[r][c] g_c, K[r][c] = 0
+                         (north_star (5) "row/column elimination"); K stays in the DMDA pattern and becomes symmetric, the
+                         solution is unchanged.  One slab: done by femasm_assemble_system; several slabs: call
+                         femasm_eliminate_columns after femasm_interface_apply. */
+} femasm_bc;
 
 typedef struct {
   double  ms_total;        /* whole call, host wall clock incl. staging               */
@@ -188,6 +196,11 @@ int femasm_assemble_interface(femasm_plan *plan, const femasm_material *material
 int femasm_interface_exchange(femasm_plan *plan, void *comm, int rank_below, int rank_above);
 /* own + received, fixed order (deterministic); Dirichlet rows are left untouched. */
 int femasm_interface_apply(femasm_plan *plan, const femasm_bc *bc, double *csr_values, double *b);
+
+/* The symmetric (row AND column) elimination of femasm_bc.symmetric as a call of its own: csr_values / b must hold the
+ * complete rows-only system of this slab (after femasm_interface_apply), DEVICE pointers; b may be NULL (columns are
+ * zeroed, nothing lifted).  No counterpart in the reference (MatZeroRowsColumns would be PETSc's). */
+int femasm_eliminate_columns(femasm_plan *plan, const femasm_bc *bc, double *csr_values, double *b);
 
 /* PETSc's default MatZeroRows storage (keepnonzeropattern off): zeroed rows keep only
  * their diagonal and the CSR arrays are recompressed.  Outputs HOST or DEVICE,

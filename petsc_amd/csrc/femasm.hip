@@ -949,6 +949,15 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
 
   // argument checks, before anything is launched
   if (bc < 0 || bc > 3) return fail(FEMASM_ERR_ARG, "unknown bc kind %d", bc);
+  const bool symmetric = bcs && bcs->symmetric != 0 && bc != FEMASM_BC_NONE;
+  if (symmetric) {
+    const int64_t SLs = (s.nsd == 3) ? s.dim[2] : s.dim[1];
+    if (p->kind == KIND_ENRICHED) return fail(FEMASM_ERR_ARG, "symmetric elimination is not offered for the enriched kind");
+    if (s.ks != 0 || s.ke != SLs)
+      return fail(FEMASM_ERR_ARG, "on a slab, call femasm_eliminate_columns after femasm_interface_apply (the rows must be complete)");
+    if (!csr_values || !is_device_ptr(csr_values) || (b && !is_device_ptr(b)))
+      return fail(FEMASM_ERR_ARG, "symmetric elimination works on device-resident csr_values / b");
+  }
   if (p->kind == KIND_ENRICHED) return assemble_enriched(p, mat, bc, csr_values, b, stats);
   if ((bc == FEMASM_BC_POISSON_INLOOP && p->kind != KIND_POISSON) ||
       (bc == FEMASM_BC_E2_COMPRESSION && p->kind != KIND_PLANE) ||
@@ -1081,6 +1090,7 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
       p->pending_fast = true;
     }
     p->pending = true;
+    if (symmetric) return femasm_eliminate_columns(p, bcs, d_vals, d_b);
     return FEMASM_OK;
   }
   t0 = std::chrono::steady_clock::now();
@@ -1145,6 +1155,7 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
   }
   p->iface_done = false;
   if (bad) return fail(FEMASM_ERR_GEOMETRY, "%llu Gauss points with non-positive or NaN det(J)", bad);
+  if (symmetric) return femasm_eliminate_columns(p, bcs, d_vals, d_b);
   return FEMASM_OK;
 }
 
@@ -1487,6 +1498,28 @@ int femasm_interface_apply(femasm_plan *p, const femasm_bc *bcs, double *csr_val
   const int64_t plane = (p->s.nsd == 3) ? p->s.dim[0] * p->s.dim[1] : p->s.dim[0];
   hipLaunchKernelGGL(k_iface_apply, dim3(nblk(plane, 4)), dim3(256), 0, p->stream, p->s, bc, csr_values, b,
                      p->recv, p->recv + p->recv_nnz);
+  HIPCHK(hipGetLastError());
+  if (!p->async) HIPCHK(hipStreamSynchronize(p->stream));
+  return FEMASM_OK;
+}
+
+int femasm_eliminate_columns(femasm_plan *p, const femasm_bc *bcs, double *csr_values, double *b) {
+  if (!p || !csr_values) return fail(FEMASM_ERR_ARG, "null argument");
+  const int bc = bcs ? bcs->kind : FEMASM_BC_NONE;
+  if (bc == FEMASM_BC_NONE) return FEMASM_OK;
+  if (p->kind == KIND_ENRICHED) return fail(FEMASM_ERR_ARG, "femasm_eliminate_columns: not offered for the enriched kind");
+  if ((bc == FEMASM_BC_POISSON_INLOOP && p->kind != KIND_POISSON) || (bc == FEMASM_BC_E2_COMPRESSION && p->kind != KIND_PLANE) ||
+      (bc == FEMASM_BC_S3_ALLFACES_EXACT && p->kind != KIND_ELASTIC) || bc < 0 || bc > 3)
+    return fail(FEMASM_ERR_ARG, "bc kind %d does not belong to problem kind %d", bc, p->kind);
+  HIPCHK(hipSetDevice(p->device));
+  if (!is_device_ptr(csr_values) || (b && !is_device_ptr(b)))
+    return fail(FEMASM_ERR_ARG, "femasm_eliminate_columns works on device-resident csr_values / b");
+  const Slab &s = p->s;
+  const int64_t SL = (s.nsd == 3) ? s.dim[2] : s.dim[1];
+  if (bc == FEMASM_BC_S3_ALLFACES_EXACT && p->cke < (s.ke + 1 < SL ? s.ke + 1 : SL))
+    return fail(FEMASM_ERR_ARG, "the coordinates must include node layer ke (the Dirichlet values of the columns above the slab)");
+  hipLaunchKernelGGL(k_eliminate_columns, dim3(nblk(p->nrows, 4)), dim3(256), 0, p->stream, s, bc, p->coords, p->nrows,
+                     p->rowptr, p->colidx, csr_values, b);
   HIPCHK(hipGetLastError());
   if (!p->async) HIPCHK(hipStreamSynchronize(p->stream));
   return FEMASM_OK;

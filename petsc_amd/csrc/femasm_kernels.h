@@ -1947,4 +1947,47 @@ __global__ __launch_bounds__(256) void k_zero_rows(int64_t n, const int64_t *row
   if (b && lane == 0) b[r] = vals ? vals[q] : 0.0;
 }
 
+// ---------------------------------------------------------------------------
+// Opt-in symmetric elimination (north_star (5) "row/column elimination"; NOT what the reference does: it zeroes rows
+// only, S3:1518 MatZeroRows(A,n,ids,1.0,0,0), P3:286-290 -- see include/femasm.h).  After the rows-only system is
+// complete: for every non-Dirichlet row r and every stored column c that is a Dirichlet dof with value g_c:
+// b[r] -= K[r][c] g_c, K[r][c] = 0.  One wave per row; the lanes' products are summed in a fixed tree (deterministic).
+// ---------------------------------------------------------------------------
+__device__ inline double dirichlet_value(const Slab &s, int bc, const double *coords, int64_t i, int64_t j, int64_t k,
+                                         int c) {
+  if (bc == BC_E2) return (c == 0) ? ((i == s.dim[0] - 1) ? -1.0 : 1.0) : 0.0;   // E2:882-885
+  if (bc == BC_S3 && c == 2) {                                                    // S3:964-968 via S3:1501-1505
+    constexpr double PI = 3.14159265358979323846264338327950288;
+    const int64_t node = i + s.dim[0] * (j + s.dim[1] * (k - s.cks));
+    return sin(PI * coords[3 * node]) * sin(PI * coords[3 * node + 1]) * sin(PI * coords[3 * node + 2]);
+  }
+  return 0.0;
+}
+__global__ __launch_bounds__(256) void k_eliminate_columns(const Slab s, int bc, const double *coords, int64_t nrows,
+                                                           const int64_t *rowptr, const int32_t *colidx, double *vals,
+                                                           double *b) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= nrows) return;
+  const int64_t M = s.dim[0], N = s.dim[1];
+  const int64_t first = (s.nsd == 3) ? M * N * s.ks : M * s.ks;
+  {
+    const int64_t n = first + r / s.dof;
+    if (is_bc_node(s, bc, n % M, (n / M) % N, n / (M * N))) return;  // Dirichlet rows stay unit rows
+  }
+  double lift = 0.0;
+  for (int64_t t = rowptr[r] + lane; t < rowptr[r + 1]; t += 64) {
+    const int64_t col = colidx[t], n = col / s.dof;
+    const int c = (int)(col - n * s.dof);
+    const int64_t i = n % M, j = (n / M) % N, k = n / (M * N);
+    if (is_bc_node(s, bc, i, j, k)) {
+      if (b) lift += vals[t] * dirichlet_value(s, bc, coords, i, j, k, c);
+      vals[t] = 0.0;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) lift += __shfl_down(lift, off);
+  if (b && lane == 0) b[r] = b[r] - lift;
+}
+
 }  // namespace femasm

@@ -33,7 +33,7 @@ EXPORTS = [
     "femasm_interface_set_buffers", "femasm_interface_apply", "femasm_compress_bc_rows", "femasm_plan_sync", "femasm_last_error",
     "femasm_version", "femasm_plan_set_fast_path", "femasm_plan_get_fast_path", "femasm_assemble_interface", "femasm_error_integrals", "femasm_fill_properties", "femasm_apply_operator",
     "femasm_coo_indices", "femasm_coord_moments", "femasm_rigid_body_modes", "femasm_zero_rows",
-    "femasm_error_integrals_static", "femasm_plan_set_enriched_contraction", "femasm_interface_exchange", "femasm_plan_set_async",
+    "femasm_error_integrals_static", "femasm_plan_set_enriched_contraction", "femasm_interface_exchange", "femasm_plan_set_async", "femasm_eliminate_columns",
 ]
 
 
@@ -59,7 +59,7 @@ class Quad(C.Structure):
 
 
 class BC(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("kind", C.c_int32), ("symmetric", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -193,14 +193,14 @@ class Plan:
         _check(load().femasm_plan_set_enriched_contraction(self._h, C.c_int(int(mode))))
 
     def assemble_system(self, values, b, material=None, bc=BC_NONE, E=0.0, nu=0.0, stride=0, e_ks=None,
-                        want_stats=False, enr_mode=0):
+                        want_stats=False, enr_mode=0, symmetric=False):
         """values / b: numpy (host) or torch (device) float64 buffers, or None.
         material: AoS GaussPointCoefficients array (numpy/torch) or None for uniform E, nu."""
         if material is None:
             mat = Material(MAT_UNIFORM, 0, 0, None, E, nu)
         else:
             mat = Material(MAT_AOS, stride, self.els if e_ks is None else e_ks, _ptr(material), E, nu, enr_mode, 0)
-        bcs = BC(bc, 0)
+        bcs = BC(bc, 1 if symmetric else 0)
         st = Stats()
         _check(load().femasm_assemble_system(self._h, C.byref(mat), C.byref(bcs), _ptr(values), _ptr(b),
                                              C.byref(st) if want_stats else None))
@@ -228,6 +228,11 @@ class Plan:
     def interface_apply(self, values, b, bc=BC_NONE):
         bcs = BC(bc, 0)
         _check(load().femasm_interface_apply(self._h, C.byref(bcs), _ptr(values), _ptr(b)))
+
+    def eliminate_columns(self, values, b, bc):
+        """opt-in symmetric elimination on a complete rows-only system (device tensors)"""
+        bcs = BC(bc, 1)
+        _check(load().femasm_eliminate_columns(self._h, C.byref(bcs), _ptr(values), _ptr(b)))
 
     def apply_operator(self, x, y, material=None, bc=BC_NONE, E=0.0, nu=0.0, stride=0, e_ks=None):
         """N4: y = K x matrix-free (device tensors; x on the plan's coordinate layers, y the owned rows)."""

@@ -344,6 +344,76 @@ def test_asynchronous_assembly_reports_geometry_errors_at_sync(env):
     plan.close()
 
 
+@pytest.mark.parametrize("kind,dims", [("p3", (6, 5, 4)), ("e2", (9, 7)), ("s3", (5, 4, 4))])
+@pytest.mark.parametrize("nslab", [1, 2])
+def test_opt_in_symmetric_elimination(env, kind, dims, nslab):
+    """femasm_bc.symmetric / femasm_eliminate_columns (NOT reference parity: the reference zeroes rows only): against
+    the elimination done in numpy on the oracle's rows-only system, and against scipy: same solution, symmetric K."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    torch, F, dev, slab = env["torch"], env["F"], env["dev"], env["slab"]
+    case = make_case(env, kind, dims)
+    M, N, P = case["dims"]
+    rp, ci = case["rp"], case["ci"]
+    n = len(rp) - 1
+    A = sp.csr_matrix((case["K"], ci, rp), shape=(n, n)).toarray()
+    b = case["b"].copy()
+    isbc = np.array([A[r, r] != 0 and np.count_nonzero(A[r]) == 1 and (kind == "p3" or A[r, r] == 1.0) for r in range(n)])
+    if kind == "p3":   # Poisson boundary rows: valence * identity, value 0
+        g = np.zeros(n)
+    else:
+        g = np.where(isbc, b, 0.0)
+    As, bs = A.copy(), b.copy()
+    for c in np.nonzero(isbc)[0]:
+        rows = ~isbc
+        bs[rows] -= A[rows, c] * g[c]
+        As[rows, c] = 0.0
+    nsd = 2 if kind == "e2" else 3
+    SL = P if nsd == 3 else N
+    if nslab == 1:
+        plan = F.Plan(case["problem"], M, N, P, coords=torch.from_numpy(case["coords"]).to(dev))
+        vals = torch.empty(plan.nnz, dtype=torch.float64, device=dev)
+        bb = torch.empty(plan.nrows, dtype=torch.float64, device=dev)
+        mat = None if case["props"] is None else torch.from_numpy(case["props"]).to(dev)
+        plan.assemble_system(vals, bb, material=mat, stride=case["stride"], bc=case["bc"], symmetric=True)
+        plan.close()
+        Kg, bg = vals.cpu().numpy(), bb.cpu().numpy()
+    else:
+        plane_e = ((M - 1) * (N - 1) if nsd == 3 else (M - 1))
+        outs, bufs, plans = [], [], []
+        for (ks, ke) in slab.slab_ranges(SL, 2):
+            cks, cke = max(ks - 1, 0), min(ke + 1, SL)
+            els, ele = slab.element_range(ks, ke)
+            co = torch.from_numpy(case["coords"].reshape(SL, -1)[cks:cke].reshape(-1).copy()).to(dev)
+            plan = F.Plan(case["problem"], M, N, P, coords=co, ks=ks, ke=ke, cks=cks, cke=cke)
+            mat = None
+            if case["props"] is not None:
+                mat = torch.from_numpy(case["props"].reshape(-1, plane_e * case["stride"])[els:ele].reshape(-1).copy()).to(dev)
+            vals = torch.empty(plan.nnz, dtype=torch.float64, device=dev)
+            bb = torch.empty(plan.nrows, dtype=torch.float64, device=dev)
+            (_, sc), (_, rc) = plan.interface_buffers()
+            send = torch.empty(max(sc, 1), dtype=torch.float64, device=dev)
+            recv = torch.empty(max(rc, 1), dtype=torch.float64, device=dev)
+            plan.interface_set_buffers(send if sc else None, recv if rc else None)
+            with pytest.raises(F.FemasmError):   # a slab's rows are not complete inside assemble_system
+                plan.assemble_system(vals, bb, material=mat, stride=case["stride"], bc=case["bc"], e_ks=els, symmetric=True)
+            plan.assemble_system(vals, bb, material=mat, stride=case["stride"], bc=case["bc"], e_ks=els)
+            plans.append(plan); outs.append((vals, bb)); bufs.append((send, recv, sc, rc))
+        bufs[0][1][:bufs[0][3]].copy_(bufs[1][0][:bufs[1][2]])
+        for r in range(2):
+            plans[r].interface_apply(outs[r][0], outs[r][1], bc=case["bc"])
+            plans[r].eliminate_columns(outs[r][0], outs[r][1], case["bc"])
+            plans[r].close()
+        Kg = np.concatenate([o[0].cpu().numpy() for o in outs])
+        bg = np.concatenate([o[1].cpu().numpy() for o in outs])
+    Ag = sp.csr_matrix((Kg, ci, rp), shape=(n, n)).toarray()
+    assert np.linalg.norm(Ag - As) <= TOL * np.linalg.norm(As) and np.linalg.norm(bg - bs) <= TOL * max(np.linalg.norm(bs), 1.0)
+    assert np.abs(Ag - Ag.T).max() <= 1e-12 * np.abs(Ag).max()                      # symmetric now
+    x_rows = spla.spsolve(sp.csc_matrix(A), b)                                        # the reference's system
+    x_sym = spla.spsolve(sp.csc_matrix(Ag), bg)
+    assert np.linalg.norm(x_rows - x_sym) <= 1e-9 * max(np.linalg.norm(x_rows), 1e-30)
+
+
 def test_compress_bc_rows_rejects_the_poisson_kind(env):
     """P3 never calls MatZeroRows: its boundary diagonal is the element valence, which the compressed form (diag 1)
     would misstate."""
