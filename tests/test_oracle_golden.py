@@ -206,3 +206,17 @@ def test_oracle_reproduces_committed_system_fixtures(O):
     for name, d in cases.items():
         for k in ("coords", "props", "K", "b"):
             assert np.array_equal(fix[name + "/" + k], d[k]), (name, k)
+
+
+def test_restatement_is_clean_under_asan_and_ubsan():
+    """the CPU restatement under -fsanitize=address,undefined (host code only).  oracle/san_check.c
+    drives every assembly routine (P3, E2, S3, the enriched kind with both PetscInt widths) on small distorted meshes
+    and re-checks two SURVEY 8(c) golden values inside the instrumented build; a sanitizer report aborts the run."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "san_check"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([os.path.join(root, "oracle", "san_check")], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "san_check: ok" in r.stdout
