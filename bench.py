@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--nel", type=int, default=0, help="elements per direction (default: 128 / 256 / 2048)")
     ap.add_argument("--perturb", action="store_true", help="general (non-affine) geometry variant")
     ap.add_argument("--uniform-material", action="store_true", help="uniform E,nu instead of the AoS array")
+    ap.add_argument("--manufactured-loads", action="store_true",
+                    help="elastic3d: FEMASM_MAT_MANUFACTURED (f and grad u evaluated in the RHS kernel, constant E, nu) "
+                         "instead of streaming the drivers' AoS records")
     ap.add_argument("--strong", action="store_true", help="fixed global mesh split over N slabs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--k-only", action="store_true", help="time K assembly only (no b)")
@@ -239,7 +242,7 @@ def main():
         if args.enr_contraction != "default":
             plan.set_enriched_contraction(1 if args.enr_contraction == "mfma" else 0)
         material = synth.props_enriched(M, N, P, coords, n_enr=args.n_enr, e0=els, e1=ele, ck0=cks, E=E, nu=nu)
-    elif wl != "poisson3d" and not args.uniform_material:
+    elif wl != "poisson3d" and not args.uniform_material and not args.manufactured_loads:
         # the drivers' GaussPointCoefficients fill (S3:1243-1363 / E2:618-670), on device (row N1)
         material = torch.empty(plan.nel * stride, dtype=torch.float64, device=dev)
         plan.fill_properties(material, E, nu, stride)
@@ -276,7 +279,7 @@ def main():
             reqs = slab.exchange_interface_start(send if rank > 0 else None, recv if rank < world - 1 else None,
                                                  rank, world)
         st = plan.assemble_system(vals, b, material=material, stride=stride, bc=bc, E=E, nu=nu, e_ks=els,
-                                  want_stats=True)
+                                  want_stats=True, manufactured=args.manufactured_loads and wl == "elastic3d")
         if world > 1:
             slab.exchange_interface_finish(reqs)
             plan.interface_apply(vals, b, bc=bc)
@@ -385,7 +388,8 @@ def main():
                                    f"{nel} per direction per GPU stacked along the slab direction (weak scaling)")),
                 "rows_per_gpu": int(st.nrows),
                 "nnz_per_gpu": int(st.nnz),
-                "material": "uniform" if material is None else f"AoS GaussPointCoefficients stride {stride}",
+                "material": ("manufactured loads evaluated in-kernel, constant E, nu" if args.manufactured_loads else
+                             "uniform") if material is None else f"AoS GaussPointCoefficients stride {stride}",
                 "parallelism": f"z-slab x{world}, interface rows exchanged over RCCL p2p" if world > 1 else "1 GPU",
             },
             "roofline": {

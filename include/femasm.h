@@ -56,7 +56,16 @@ typedef struct {
 
 /* "material": per-element GaussPointCoefficients array (A14), zero-copy from
  * VecGetArray(properties) (E2:29-35, S3:51-64, R3:52-68), or uniform constants. */
-enum { FEMASM_MAT_AOS = 0, FEMASM_MAT_UNIFORM = 1 };
+enum {
+  FEMASM_MAT_AOS = 0,
+  FEMASM_MAT_UNIFORM = 1,
+  /* S3/R3 only, no counterpart in the reference: E, nu constant (the drivers' -iso_E / -iso_nu, S3:1311-1314) and the
+   * loads of the drivers' manufactured solution (evaluate_Elastic, S3:958-985) evaluated inside the right-hand-side
+   * kernel at the Gauss-point positions it derives from the coordinates -- the fill loop S3:1243-1363 and the
+   * 2 304 bytes per element that AssembleF_Elasticity (S3:720-803) reads back from it are not needed.  Same b as from
+   * the records the drivers fill, to rounding.  FEMASM_MAT_AOS stays the drop-in default. */
+  FEMASM_MAT_MANUFACTURED = 2
+};
 typedef struct {
   int32_t layout;       /* FEMASM_MAT_AOS | FEMASM_MAT_UNIFORM (K only needs E,nu)            */
   int32_t stride;       /* doubles per element: 24 (E2) | 400 (S3) | 408/416 (R3)             */

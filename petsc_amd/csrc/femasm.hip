@@ -457,6 +457,8 @@ int launch_rhs(femasm_plan *p, const femasm_material *mat, int bc, double *out, 
   a.iface = iface;
   a.bad = p->bad;
   a.rect = p->rect_checked ? 1 : 0;
+  a.E = mat ? mat->E : 0.0;
+  a.nu = mat ? mat->nu : 0.0;
   // S3/R3 with the reference's AoS records as 16-byte runs: streaming element pass + in-wave part of the node sum
   // (k_rhs_elem_elastic_runs); anything else (uniform material: no loads; an odd stride or base) takes the
   // thread-per-element kernel and the element-vector form of the gather
@@ -505,6 +507,9 @@ int launch_rhs(femasm_plan *p, const femasm_material *mat, int bc, double *out, 
       if (a.rect) hipLaunchKernelGGL(k_rhs_elem_elastic_runs<true>, grid(1), dim3(64), 0, p->stream, sl, a);
       hipLaunchKernelGGL(k_rhs_elem_elastic_runs<false>, grid(0), dim3(64), 0, p->stream, sl, a);
     }
+    else if (KIND == KIND_ELASTIC && a.mat_layout == FEMASM_MAT_MANUFACTURED)
+      hipLaunchKernelGGL(k_rhs_elem_s3_manufactured, dim3(nblk(nel, 128) < 65536u ? nblk(nel, 128) : 65536u), dim3(128), 0,
+                         p->stream, sl, a);
     else
       hipLaunchKernelGGL(k_rhs_elem<KIND>, dim3(nblk(nel) < 16384u ? nblk(nel) : 16384u), dim3(256), 0, p->stream, sl, a);
     HIPCHK(hipGetLastError());
@@ -973,7 +978,7 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
       if (mloc.stride < need) return fail(FEMASM_ERR_ARG, "material stride %d < %d", mloc.stride, need);
       if (mloc.e_ks > s.els) return fail(FEMASM_ERR_ARG, "material starts at element layer %lld > %lld",
                                          (long long)mloc.e_ks, (long long)s.els);
-    } else if (mloc.layout != FEMASM_MAT_UNIFORM) {
+    } else if (mloc.layout != FEMASM_MAT_UNIFORM && !(mloc.layout == FEMASM_MAT_MANUFACTURED && p->kind == KIND_ELASTIC)) {
       return fail(FEMASM_ERR_ARG, "unknown material layout %d", mloc.layout);
     }
     p->s.mat_e_ks = (mloc.layout == FEMASM_MAT_AOS) ? mloc.e_ks : s.els;
@@ -1205,7 +1210,7 @@ int femasm_assemble_interface(femasm_plan *p, const femasm_material *mat, const 
         return fail(FEMASM_ERR_ARG, "femasm_assemble_interface needs the material array in device memory");
       if (mloc.stride < need) return fail(FEMASM_ERR_ARG, "material stride %d < %d", mloc.stride, need);
       if (mloc.e_ks > p->s.els) return fail(FEMASM_ERR_ARG, "material starts above the first assembled element layer");
-    } else if (mloc.layout != FEMASM_MAT_UNIFORM) {
+    } else if (mloc.layout != FEMASM_MAT_UNIFORM && !(mloc.layout == FEMASM_MAT_MANUFACTURED && p->kind == KIND_ELASTIC)) {
       return fail(FEMASM_ERR_ARG, "unknown material layout %d", mloc.layout);
     }
     p->s.mat_e_ks = (mloc.layout == FEMASM_MAT_AOS) ? mloc.e_ks : p->s.els;
@@ -1285,7 +1290,7 @@ int femasm_apply_operator(femasm_plan *p, const femasm_material *mat, const fema
       const int need = (p->kind == KIND_PLANE) ? 24 : 400;
       if (!mloc.gp || !is_device_ptr(mloc.gp) || mloc.stride < need || mloc.e_ks > p->s.els)
         return fail(FEMASM_ERR_ARG, "femasm_apply_operator needs a device material array covering the slab's elements");
-    } else if (mloc.layout != FEMASM_MAT_UNIFORM) {
+    } else if (mloc.layout != FEMASM_MAT_UNIFORM && !(mloc.layout == FEMASM_MAT_MANUFACTURED && p->kind == KIND_ELASTIC)) {
       return fail(FEMASM_ERR_ARG, "unknown material layout %d", mloc.layout);
     }
     p->s.mat_e_ks = (mloc.layout == FEMASM_MAT_AOS) ? mloc.e_ks : p->s.els;

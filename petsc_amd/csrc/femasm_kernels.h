@@ -611,6 +611,7 @@ struct RArgs {
   const double *x;          // N4 operator apply: input vector on the node layers of coords (else null)
   int32_t rect;             // the rectilinearity pre-pass ran in this call: bad[3] == 0 <=> every element is a box
   int32_t runs;             // elemF holds the records of k_rhs_elem_elastic_runs, not element vectors
+  double E, nu;             // FEMASM_MAT_MANUFACTURED: the drivers' -iso_E / -iso_nu
 };
 
 template <int KIND>
@@ -743,6 +744,120 @@ __device__ inline void rhs_elem_one(const Slab &s, const RArgs &a, int64_t e) {
     else a.elemF[ef_idx<NOUT>(e, q)] = F[q];
   }
 }
+// ---------------------------------------------------------------------------
+// FEMASM_MAT_MANUFACTURED (S3/R3): the loads of the drivers' manufactured solution evaluated HERE instead of being
+// streamed from the 3 200-byte records the drivers fill with them (S3:1243-1363 fill -> S3:720-803 use): per element
+// the positions of the 8 + 24 Gauss points (S3:1271-1303), body force and displacement gradient of
+// u = (0, 0, sin pi x sin pi y sin pi z) (evaluate_Elastic, S3:958-985) with the drivers' constant E, nu, then Fe + Ge
+// exactly as from a record (S3:520-656).  An axis-aligned box (tested exactly per element) needs the sines and cosines
+// of only 4 abscissae per axis (2 Gauss, 2 ends): 12 sincospi instead of 96.  sincospi(x) for sin(pi x): rounding only.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_rhs_elem_s3_manufactured(const Slab s, const RArgs a) {
+  constexpr double PI = 3.14159265358979323846264338327950288;
+  const int64_t M = s.dim[0], N = s.dim[1];
+  const int64_t mx = M - 1, my = N - 1;
+  const double E = a.E, nu = a.nu;
+  const double den = 2 * nu * nu + nu - 1;
+  const double factor = E * (1 - nu) / ((1.0 + nu) * (1.0 - 2.0 * nu));
+  const double d11 = factor * 1.0, d12 = factor * (nu / (1 - nu)), d44 = factor * (0.5 * (1 - 2 * nu) / (1 - nu));
+  for (int64_t e = (int64_t)blockIdx.x * 128 + threadIdx.x; e < a.nel; e += (int64_t)gridDim.x * 128) {
+    const int64_t ex = e % mx, ey = (e / mx) % my, ez = s.els + e / (mx * my);
+    double xc[24];
+#pragma unroll
+    for (int n = 0; n < 8; n++) {
+      const int64_t node = (ex + HDI[n]) + M * ((ey + HDJ[n]) + N * (ez + HDK[n] - s.cks));
+#pragma unroll
+      for (int d = 0; d < 3; d++) xc[3 * n + d] = a.coords[3 * node + d];
+    }
+    bool box = true;
+#pragma unroll
+    for (int n = 0; n < 8; n++)
+      box = box && xc[3 * n] == xc[3 * (HDI[n] ? 3 : 0)] && xc[3 * n + 1] == xc[3 * (HDJ[n] ? 1 : 0) + 1] &&
+            xc[3 * n + 2] == xc[3 * (HDK[n] ? 4 : 0) + 2];
+    double F[24];
+#pragma unroll
+    for (int q = 0; q < 24; q++) F[q] = 0.0;
+    const double dx = fabs(xc[0] - xc[9]), dy = fabs(xc[1] - xc[4]), dz = fabs(xc[2] - xc[14]);  // S3:560-562
+    // sin / cos of pi * coordinate at the abscissae of one axis: index 0: -g, 1: +g, 2: lower end, 3: upper end
+    double sn[3][4], cs[3][4];
+    if (box) {
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        const double lo = xc[d], hi = xc[(d == 0 ? 9 : (d == 1 ? 3 : 12)) + d];
+        const double a0 = 0.5 * (1.0 + GAUSS_G), a1 = 0.5 * (1.0 - GAUSS_G);
+        sincospi(a0 * lo + a1 * hi, &sn[d][0], &cs[d][0]);
+        sincospi(a1 * lo + a0 * hi, &sn[d][1], &cs[d][1]);
+        sincospi(lo, &sn[d][2], &cs[d][2]);
+        sincospi(hi, &sn[d][3], &cs[d][3]);
+      }
+    }
+    // body force at the volume Gauss points (S3:1304-1330 fill, S3:534-545 use)
+    for (int p = 0; p < 8; p++) {
+      double sx, cx, sy, cy, sz, cz, fac;
+      if (box) {
+        sx = sn[0][HDI[p]]; cx = cs[0][HDI[p]]; sy = sn[1][HDJ[p]]; cy = cs[1][HDJ[p]]; sz = sn[2][HDK[p]]; cz = cs[2][HDK[p]];
+        fac = 1.0 * ((0.5 * (xc[9] - xc[0])) * (0.5 * (xc[4] - xc[1])) * (0.5 * (xc[14] - xc[2])));
+      } else {
+        double pos[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int n = 0; n < 8; n++)
+#pragma unroll
+          for (int d = 0; d < 3; d++) pos[d] = pos[d] + c_tab3.N[p][n] * xc[3 * n + d];
+        sincospi(pos[0], &sx, &cx); sincospi(pos[1], &sy, &cy); sincospi(pos[2], &sz, &cz);
+        fac = 1.0 * det3_only(c_tab3.G[p], xc);
+      }
+      const double fx = (E * PI * PI * cx * cz * sy) / (2 * den);            // S3:972-977
+      const double fy = (E * PI * PI * cy * sx * cz) / (2 * den);
+      const double fz = (E * PI * PI * sx * sy * sz * (3 * nu - 2)) / den;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        F[3 * i] += fac * c_tab3.N[p][i] * fx;
+        F[3 * i + 1] += fac * c_tab3.N[p][i] * fy;
+        F[3 * i + 2] += fac * c_tab3.N[p][i] * fz;
+      }
+    }
+    // natural-BC term: grad u_z at the 24 face Gauss points (S3:1331-1363 fill, S3:568-648 use); u_x = u_y = 0
+    for (int p = 0; p < 24; p++) {
+      const int axis = p / 8, q = p & 3;
+      const double side = ((p / 4) % 2 == 0) ? 1.0 : -1.0;
+      double sx, cx, sy, cy, sz, cz;
+      if (box) {
+        // face point: the face's axis sits at an end (+1 face: upper), the two free axes at -g/+g in the order of S3:256-284
+        const int a0 = (axis == 0) ? 1 : 0, a1 = (axis == 2) ? 1 : 2;
+        int idx[3];
+        idx[axis] = (side > 0.0) ? 3 : 2;
+        idx[a0] = q & 1;
+        idx[a1] = q >> 1;
+        sx = sn[0][idx[0]]; cx = cs[0][idx[0]]; sy = sn[1][idx[1]]; cy = cs[1][idx[1]]; sz = sn[2][idx[2]]; cz = cs[2][idx[2]];
+      } else {
+        double pos[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int n = 0; n < 8; n++)
+#pragma unroll
+          for (int d = 0; d < 3; d++) pos[d] = pos[d] + c_tab3.NF[p][n] * xc[3 * n + d];
+        sincospi(pos[0], &sx, &cx); sincospi(pos[1], &sy, &cy); sincospi(pos[2], &sz, &cz);
+      }
+      const double g0 = PI * cx * sy * sz, g1 = PI * sx * cy * sz, g2 = PI * sx * sy * cz;  // grad u_z, S3:978-983
+      const double z0 = d12 * g2, z1 = d12 * g2, z2 = d11 * g2;   // strains: e2 = g2, e4 = g1, e5 = g0, the others 0
+      const double z4 = d44 * g1, z5 = d44 * g0;
+      double t[3], Jp;
+      if (axis == 0)      { t[0] = z0 * side; t[1] = 0.0 * side; t[2] = z5 * side; Jp = (0.5 * dy) * (0.5 * dz); }
+      else if (axis == 1) { t[0] = 0.0 * side; t[1] = z1 * side; t[2] = z4 * side; Jp = (0.5 * dx) * (0.5 * dz); }
+      else                { t[0] = z5 * side; t[1] = z4 * side; t[2] = z2 * side; Jp = (0.5 * dx) * (0.5 * dy); }
+      const double fac = 1.0 * Jp;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const double w = fac * c_tab3.NF[p][i];
+        F[3 * i] += w * t[0];
+        F[3 * i + 1] += w * t[1];
+        F[3 * i + 2] += w * t[2];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 24; q++) a.elemF[ef_idx<24>(e, q)] = F[q];
+  }
+}
+
 // grid-stride over the elements (a capped grid: the kernel is also launched when it only has to find out, on the
 // device, that the rectilinear P3 path has already written b)
 template <int KIND>

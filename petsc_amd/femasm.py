@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FEMASM_LIB", os.path.join(_HERE, "csrc", "libfemasm.so"))  # override: kernel experiments
 
 POISSON3D_Q1, PLANE_STRAIN2D_Q1, ELASTIC3D_Q1, ELASTIC3D_ENRICHED = 0, 1, 2, 3
-MAT_AOS, MAT_UNIFORM = 0, 1
+MAT_AOS, MAT_UNIFORM, MAT_MANUFACTURED = 0, 1, 2
 BC_NONE, BC_POISSON_INLOOP, BC_E2_COMPRESSION, BC_S3_ALLFACES_EXACT = 0, 1, 2, 3
 
 _TRAITS = {  # kind: (nsd, dof, nen, ngp)
@@ -193,11 +193,11 @@ class Plan:
         _check(load().femasm_plan_set_enriched_contraction(self._h, C.c_int(int(mode))))
 
     def assemble_system(self, values, b, material=None, bc=BC_NONE, E=0.0, nu=0.0, stride=0, e_ks=None,
-                        want_stats=False, enr_mode=0, symmetric=False):
+                        want_stats=False, enr_mode=0, symmetric=False, manufactured=False):
         """values / b: numpy (host) or torch (device) float64 buffers, or None.
         material: AoS GaussPointCoefficients array (numpy/torch) or None for uniform E, nu."""
         if material is None:
-            mat = Material(MAT_UNIFORM, 0, 0, None, E, nu)
+            mat = Material(MAT_MANUFACTURED if manufactured else MAT_UNIFORM, 0, 0, None, E, nu)
         else:
             mat = Material(MAT_AOS, stride, self.els if e_ks is None else e_ks, _ptr(material), E, nu, enr_mode, 0)
         bcs = BC(bc, 1 if symmetric else 0)

@@ -414,6 +414,40 @@ def test_opt_in_symmetric_elimination(env, kind, dims, nslab):
     assert np.linalg.norm(x_rows - x_sym) <= 1e-9 * max(np.linalg.norm(x_rows), 1e-30)
 
 
+@pytest.mark.parametrize("dims,perturb", [((7, 6, 5), False), ((7, 6, 5), True), ((20, 9, 35), False), ((4, 3, 9), True)])
+@pytest.mark.parametrize("nslab", [1, 2])
+def test_manufactured_loads_layout_equals_the_records_the_drivers_fill(env, dims, perturb, nslab):
+    """FEMASM_MAT_MANUFACTURED: f and grad u evaluated in the right-hand-side kernel; b (and K) against the oracle
+    assembling from the oracle's own fill of the records (S3:1243-1363), 1e-13."""
+    torch, F, dev, slab = env["torch"], env["F"], env["dev"], env["slab"]
+    case = make_case(env, "s3", dims, perturb=perturb)
+    M, N, P = case["dims"]
+    Ks, bs = [], []
+    for (ks, ke) in slab.slab_ranges(P, nslab):
+        cks, cke = max(ks - 1, 0), min(ke + 1, P)
+        co = torch.from_numpy(case["coords"].reshape(P, -1)[cks:cke].reshape(-1).copy()).to(dev)
+        plan = F.Plan(F.ELASTIC3D_Q1, M, N, P, coords=co, ks=ks, ke=ke, cks=cks, cke=cke)
+        vals = torch.full((plan.nnz,), float("nan"), dtype=torch.float64, device=dev)
+        b = torch.full((plan.nrows,), float("nan"), dtype=torch.float64, device=dev)
+        plan.assemble_system(vals, b, E=90.0, nu=0.28, bc=F.BC_S3_ALLFACES_EXACT, manufactured=True)
+        Ks.append((plan, vals, b))
+    for r in range(nslab - 1):
+        (_, sc), _ = Ks[r + 1][0].interface_buffers()
+        recv = torch.empty(sc, dtype=torch.float64, device=dev)
+        send = torch.empty(sc, dtype=torch.float64, device=dev)   # caller-owned wire buffer: assemble again into it
+        Ks[r + 1][0].interface_set_buffers(send, None)
+        Ks[r + 1][0].assemble_system(Ks[r + 1][1], Ks[r + 1][2], E=90.0, nu=0.28, bc=F.BC_S3_ALLFACES_EXACT, manufactured=True)
+        recv.copy_(send)
+        Ks[r][0].interface_set_buffers(None, recv)
+    for r in range(nslab):
+        Ks[r][0].interface_apply(Ks[r][1], Ks[r][2], bc=F.BC_S3_ALLFACES_EXACT)
+    K = np.concatenate([k[1].cpu().numpy() for k in Ks])
+    b = np.concatenate([k[2].cpu().numpy() for k in Ks])
+    for k in Ks:
+        k[0].close()
+    assert rel(K, case["K"]) <= TOL and rel(b, case["b"]) <= TOL, (rel(K, case["K"]), rel(b, case["b"]))
+
+
 def test_compress_bc_rows_rejects_the_poisson_kind(env):
     """P3 never calls MatZeroRows: its boundary diagonal is the element valence, which the compressed form (diag 1)
     would misstate."""
