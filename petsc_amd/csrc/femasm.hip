@@ -163,6 +163,7 @@ struct femasm_plan {
   int rhs_wg_per_cu[2] = {0, 0};       // resident workgroups per CU of k_rhs_elem_elastic_runs<false / true>
   bool rect_checked = false;           // k_check_rectilinear ran on the stream in this call (its verdict is bad[3])
   bool cond_general = false;           // launch_K: the general kernels are launched with KArgs::cond set
+  bool cond_rhs = false;               // launch_rhs (E2): k_rhs_e2_fused is launched with RArgs::cond set
   bool iface_rect = false;             // femasm_assemble_interface ran the rectilinearity check: its verdict carries over
   bool iface_done = false;             // femasm_assemble_interface already filled the send buffer for the next call
   bool time_main = false;              // record ev[4], ev[5] around the dominant K kernel of the main pass
@@ -179,6 +180,8 @@ struct femasm_plan {
   int64_t stage_u_count = 0;
   double *static_scratch = nullptr;    // this device's copy of the file-scope `scratch` array (femasm_error_integrals_static)
 
+  double *e2_bout = nullptr;           // E2 one-pass form: launch_K hands this b array to k_assemble_e2_rect ...
+  int64_t e2_b0 = 0, e2_b1 = 0;        // ... which then wrote b of the node rows [e2_b0, e2_b1)
   bool async = false;                  // femasm_plan_set_async: assemble_system / interface_apply do not wait for the device
   bool pending = false;                // an asynchronous call has not had its flags read yet (femasm_plan_sync does it)
   bool pending_fast = false;           // ... and it used a fast kernel (premise flag bad[1] decides the plan's level)
@@ -285,16 +288,25 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
       const Box b{1, M - 1, 0, 1, y0, y1};
       KArgs a = make_kargs<KIND>(p, mat, bc, out, b, s0, iface);
       a.ends = (bc == FEMASM_BC_E2_COMPRESSION) ? 1 : 0;  // the kernel also writes the Dirichlet rows of the columns i = 0, M-1
+      // one-pass form: b of these node rows from the same sweep over the records (AoS records with 16-byte alignment)
+      static const bool no_fuse = getenv("FEMASM_E2_TWO_PASS") != nullptr;
+      if (p->e2_bout && a.ends && aos2 && !no_fuse && ((uintptr_t)p->e2_bout & 15) == 0) {
+        a.bout = p->e2_bout;
+        p->e2_b0 = y0;
+        p->e2_b1 = y1;
+      }
       dim3 grid((unsigned)((b.x1 - b.x0 + RS2_TX - 1) / RS2_TX), (unsigned)((y1 - y0 + E2W_YC - 1) / E2W_YC), 1);
       if (timed) HIPCHK(hipEventRecord(p->ev[4], p->stream));
-      hipLaunchKernelGGL(k_assemble_e2_rect, grid, dim3(64), 0, p->stream, p->s, a);
+      if (a.bout) hipLaunchKernelGGL(k_assemble_e2_rect<true>, grid, dim3(64), 0, p->stream, p->s, a);
+      else hipLaunchKernelGGL(k_assemble_e2_rect<false>, grid, dim3(64), 0, p->stream, p->s, a);
       HIPCHK(hipGetLastError());
       p->used_fast = true;
       if (timed) {
         HIPCHK(hipEventRecord(p->ev[5], p->stream));
         const double nint = (double)(M - 2) * (double)(y1 - y0);
         // stores of the interior rows + E,nu at the Gauss points (the coordinates are read by the pre-pass)
-        p->bytes_main = 8.0 * nint * 36.0 + (aos2 ? 16.0 * 4.0 * (double)(M - 1) * (y1 - y0 + 1) : 0.0);
+        p->bytes_main = 8.0 * nint * 36.0 + (aos2 ? 16.0 * 4.0 * (double)(M - 1) * (y1 - y0 + 1) : 0.0) +
+                        (a.bout ? 16.0 * 4.0 * (double)(M - 1) * (y1 - y0 + 1) + 16.0 * (double)M * (y1 - y0) : 0.0);
       }
       // the four edges of the node grid (Dirichlet columns i = 0, M-1 and the rows j = 0, N-1): brick kernel
       int rc2 = 0;
@@ -459,6 +471,7 @@ int launch_rhs(femasm_plan *p, const femasm_material *mat, int bc, double *out, 
   a.rect = p->rect_checked ? 1 : 0;
   a.E = mat ? mat->E : 0.0;
   a.nu = mat ? mat->nu : 0.0;
+  a.cond = p->cond_rhs ? 1 : 0;
   // S3/R3 with the reference's AoS records as 16-byte runs: streaming element pass + in-wave part of the node sum
   // (k_rhs_elem_elastic_runs); anything else (uniform material: no loads; an odd stride or base) takes the
   // thread-per-element kernel and the element-vector form of the gather
@@ -1054,16 +1067,26 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
   p->used_fast = false;
   p->time_main = stats != nullptr;
   p->bytes_main = 0.0;
+  p->e2_bout = (p->kind == KIND_PLANE && d_vals && d_b) ? d_b : nullptr;
+  p->e2_b0 = p->e2_b1 = 0;
   if (d_vals) {
     rc = run_K();
     if (rc) return rc;
   }
+  p->e2_bout = nullptr;  // (the conditional and fallback passes below assemble K only)
   if (stats) HIPCHK(hipEventRecord(p->ev[1], p->stream));
   // ---- b ----
   if (d_b) {
     switch (p->kind) {
       case KIND_POISSON: rc = launch_rhs<KIND_POISSON>(p, &mloc, bc, d_b, s.ks, s.ke, 0, true); break;
-      case KIND_PLANE:   rc = launch_rhs<KIND_PLANE>(p, &mloc, bc, d_b, s.ks, s.ke, 0, true); break;
+      case KIND_PLANE:
+        if (p->e2_b1 > p->e2_b0) {  // the stiffness kernel wrote b of the node rows [e2_b0, e2_b1): the rows around them
+          rc = launch_rhs<KIND_PLANE>(p, &mloc, bc, d_b, s.ks, p->e2_b0, 0, true);
+          if (!rc) rc = launch_rhs<KIND_PLANE>(p, &mloc, bc, d_b + 2 * s.dim[0] * (p->e2_b1 - s.ks), p->e2_b1, s.ke, 0, true);
+        } else {
+          rc = launch_rhs<KIND_PLANE>(p, &mloc, bc, d_b, s.ks, s.ke, 0, true);
+        }
+        break;
       case KIND_ELASTIC: rc = launch_rhs<KIND_ELASTIC>(p, &mloc, bc, d_b, s.ks, s.ke, 0, true); break;
     }
     if (rc) return rc;
@@ -1093,6 +1116,12 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
       p->fast_level = level;
       if (rc) return rc;
       p->pending_fast = true;
+      if (p->e2_b1 > p->e2_b0) {  // b of the one-pass kernel's rows again, on the device's verdict
+        p->cond_rhs = true;
+        rc = launch_rhs<KIND_PLANE>(p, &mloc, bc, d_b + 2 * s.dim[0] * (p->e2_b0 - s.ks), p->e2_b0, p->e2_b1, 0, true);
+        p->cond_rhs = false;
+        if (rc) return rc;
+      }
     }
     p->pending = true;
     if (symmetric) return femasm_eliminate_columns(p, bcs, d_vals, d_b);
@@ -1122,6 +1151,12 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
     t0 = std::chrono::steady_clock::now();
     rc = run_K();
     if (rc) return rc;
+    if (p->e2_b1 > p->e2_b0) {  // the one-pass kernel's premise failed: its b rows again, by the general kernel
+      rc = launch_rhs<KIND_PLANE>(p, &mloc, bc, d_b + 2 * s.dim[0] * (p->e2_b0 - s.ks), p->e2_b0, p->e2_b1, 0, true);
+      if (rc) return rc;
+      p->e2_b0 = p->e2_b1 = 0;
+      if (b_host) HIPCHK(hipMemcpyAsync(b, d_b, p->nrows * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    }
     HIPCHK(hipMemcpyAsync(flags, p->bad, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     k_ms_redo = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

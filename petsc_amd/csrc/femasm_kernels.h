@@ -134,6 +134,7 @@ struct KArgs {
   int32_t zc;             // row-sweep kernels: node layers (rows in 2-D) per workgroup
   int32_t rect;           // row-sweep kernels: the mesh was verified rectilinear (k_check_rectilinear): geometry from 1-D lines
   int32_t ends;           // the interior kernel writes the Dirichlet rows of the x-end nodes of its lines; k_bc_rows skips them
+  double *bout;           // k_assemble_e2_rect: also write b of its node rows (E2 one-pass form), or null
   int32_t cond;           // general kernels: run only if bad[1] != 0, i.e. the fast kernel launched before on the same rows
                           // found its premise broken (femasm_assemble_interface: no host round trip)
 };
@@ -612,6 +613,7 @@ struct RArgs {
   int32_t rect;             // the rectilinearity pre-pass ran in this call: bad[3] == 0 <=> every element is a box
   int32_t runs;             // elemF holds the records of k_rhs_elem_elastic_runs, not element vectors
   double E, nu;             // FEMASM_MAT_MANUFACTURED: the drivers' -iso_E / -iso_nu
+  int32_t cond;             // k_rhs_e2_fused: run only if bad[1] != 0 (the one-pass kernel's premise failed: b again)
 };
 
 template <int KIND>
@@ -1420,6 +1422,7 @@ __device__ inline void e2r_load(const Slab &s, const RArgs &a, int64_t exc, int6
 
 template <bool ALIGNED, bool LIVE /* AoS material and at least one element row: else every Fe is zero */>
 __global__ __launch_bounds__(256) void k_rhs_e2_fused(const Slab s, const RArgs a) {
+  if (a.cond && a.bad[1] == 0) return;
   const int64_t M = s.dim[0], mx = M - 1;
   const int lane = threadIdx.x & 63;
   const int64_t n0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 63;

@@ -1203,9 +1203,18 @@ constexpr int RS2_ROW = 18, RS2_NB = 36;  // values of a CSR row / of a node blo
 // accumulators; the six record numbers of an element follow from the two coordinate lines and its (E,nu) (read by
 // the lanes either side of it one step ahead, all four Gauss points compared bitwise: bad[1] on a mismatch), with
 // the operations of k_assemble_rowsweep2d's record wave in the same order.  No record wave, no hand-shake.
+// FUSE = true, the one-pass form (KArgs::bout): the wave also integrates the right-hand side of its nodes (E2:325-350,
+// 461-529).  The body force fx[4], fy[4] sits in the 64 bytes after E[4], nu[4] of the same 192-byte record, so the
+// separate RHS pass and its second sweep over the records disappear: per element row every lane forms, for the
+// elements left and right of its node, the Fe entries of the element's lower node on its column (used now) and upper
+// node (kept for the next node row), and adds the node's four terms in the reference's element order.
+// Measured at 2048^2: the fused kernel is 0.10 ms slower than the plain one and the pass it replaces
+// takes 0.15 ms, so the step gains 7 %; selectable (FEMASM_E2_TWO_PASS=1 keeps the two-pass form).
 // ---------------------------------------------------------------------------
 constexpr int E2W_YC = 32;
+template <bool FUSE>
 __global__ __launch_bounds__(64) void k_assemble_e2_rect(const Slab s, const KArgs a) {
+  constexpr int NM = FUSE ? 16 : 8;
   constexpr int NB = RS2_NB, RUN = RS2_TX * NB, END = 24;  // END: values of the two rows of an x-end node (2 x 3 neighbours x 2 x 2)
   __shared__ __attribute__((aligned(16))) double sh_stage[END + RUN + END];
   const int lane = threadIdx.x;
@@ -1228,20 +1237,44 @@ __global__ __launch_bounds__(64) void k_assemble_e2_rect(const Slab s, const KAr
     return a.coords[2 * (M * (j - s.cks)) + 1];
   };
   // E[4], nu[4] of the elements i-1, i of element row L (clamped to the rows this rank holds: never masked)
-  auto load_mat = [&](int64_t L, double (*m)[8]) {
+  auto load_mat = [&](int64_t L, double (*m)[NM]) {
     if (!aos) return;
     const int64_t Lc = L < s.els ? s.els : (L > s.ele - 1 ? s.ele - 1 : L);
 #pragma unroll
     for (int ox = 0; ox < 2; ox++) {
       const double *mq = a.gp + ((i - 1 + ox) + (M - 1) * (Lc - s.mat_e_ks)) * a.mat_stride + 8;
 #pragma unroll
-      for (int q = 0; q < 8; q++) m[ox][q] = mq[q];
+      for (int q = 0; q < NM; q++) m[ox][q] = mq[q];
+    }
+  };
+  // Fe entries (E2:339-349: Fe[2n+c] += (fac N_n) f_c, Gauss points in order) of the element ox of row L at its lower
+  // node on this lane's column (ox = 0: local node 3, ox = 1: node 0) and at its upper node (ox = 0: node 2, ox = 1: node 1)
+  auto fe_terms = [&](int64_t L, double ylo, double yhi, const double (*m)[NM], double (*lo)[2], double (*up)[2]) {
+    const bool rowok = aos && L >= s.els && L < s.ele;
+    const double J11 = rowok ? 0.5 * (yhi - ylo) : 0.0;
+#pragma unroll
+    for (int ox = 0; ox < 2; ox++) {
+      const double fac = 1.0 * (Jx[ox] * J11);
+      const int nlo = ox ? 0 : 3, nup = ox ? 1 : 2;
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        double vl = 0.0, vu = 0.0;
+#pragma unroll
+        for (int pp = 0; pp < 4; pp++) {
+          vl += fac * c_tab2.N[pp][nlo] * m[ox][(NM - 8) + 4 * c + pp];
+          vu += fac * c_tab2.N[pp][nup] * m[ox][(NM - 8) + 4 * c + pp];
+        }
+        lo[ox][c] = rowok ? vl : 0.0;
+        up[ox][c] = rowok ? vu : 0.0;
+      }
     }
   };
   // records (pd0, pd1, pe0, pe1, po, pq) of the elements i-1, i of element row L
-  auto records = [&](int64_t L, const double (*m)[8], double (*rec)[6]) {
+  // (ylo, yhi = the y line at node rows L and L+1: requested a step ahead like the material, so that no load of the
+  // step's own sits on its critical path)
+  auto records = [&](int64_t L, double ylo, double yhi, const double (*m)[NM], double (*rec)[6]) {
     const bool rowok = L >= s.els && L < s.ele;
-    const double J11 = rowok ? 0.5 * (yline(L + 1) - yline(L)) : 1.0;
+    const double J11 = rowok ? 0.5 * (yhi - ylo) : 1.0;
     const double ay = 1.0 / J11;
 #pragma unroll
     for (int ox = 0; ox < 2; ox++) {
@@ -1266,22 +1299,52 @@ __global__ __launch_bounds__(64) void k_assemble_e2_rect(const Slab s, const KAr
       rec[ox][5] = rowok ? d44 * (ax[ox] * ay) : 0.0;
     }
   };
-  double mcur[2][8], mnext[2][8], rlo[2][6], rhi[2][6];
+  double mcur[2][NM], mnext[2][NM], rlo[2][6], rhi[2][6];
+  double fup[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, flo[2][2];  // Fe of the element row below at its upper nodes; scratch
 #pragma unroll
   for (int ox = 0; ox < 2; ox++)
 #pragma unroll
-    for (int q = 0; q < 8; q++) mcur[ox][q] = mnext[ox][q] = 0.0;
+    for (int q = 0; q < NM; q++) mcur[ox][q] = mnext[ox][q] = 0.0;
   load_mat(yc0 - 1, mcur);
-  records(yc0 - 1, mcur, rlo);
+  double y0 = yline(yc0 - 1), y1 = yline(yc0), y2 = yline(yc0 + 1);  // rolling window of the y line: rows L, L+1, L+2
+  records(yc0 - 1, y0, y1, mcur, rlo);
+  if constexpr (FUSE) fe_terms(yc0 - 1, y0, y1, mcur, flo, fup);
   load_mat(yc0, mnext);
   for (int st = 0; st < ny; st++) {
     const int64_t jn = yc0 + st;
 #pragma unroll
     for (int ox = 0; ox < 2; ox++)
 #pragma unroll
-      for (int q = 0; q < 8; q++) mcur[ox][q] = mnext[ox][q];
+      for (int q = 0; q < NM; q++) mcur[ox][q] = mnext[ox][q];
     load_mat(jn + 1, mnext);  // one step ahead: issued before this step's stores
-    records(jn, mcur, rhi);
+    y0 = y1;
+    y1 = y2;
+    y2 = yline(jn + 2);
+    records(jn, y0, y1, mcur, rhi);
+    if constexpr (FUSE) {
+      double nup[2][2];
+      fe_terms(jn, y0, y1, mcur, flo, nup);
+      double bv[2];
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        double v = 0.0 + fup[0][c];   // element (i-1, j-1), its node (1,1)
+        v = v + fup[1][c];            // element (i,   j-1), its node (0,1)
+        v = v + flo[0][c];            // element (i-1, j  ), its node (1,0)
+        v = v + flo[1][c];            // element (i,   j  ), its node (0,0)
+        bv[c] = v;
+        fup[0][c] = nup[0][c];
+        fup[1][c] = nup[1][c];
+      }
+      double *bo = a.bout + 2 * (M * (jn - s.ks));
+#if FEMASM_EXP == 5  // profiling build: the one-pass kernel without its b stores
+      asm volatile("" ::"v"(bv[0]), "v"(bv[1]));
+#else
+      if (lane < nvx) *reinterpret_cast<double2 *>(bo + 2 * i) = make_double2(bv[0], bv[1]);
+#endif
+      // the Dirichlet columns i = 0, M-1 of this node row (E2:882-885: ux = +1 / -1, uy = 0), with the first / last run
+      if (pre && lane == 0) *reinterpret_cast<double2 *>(bo) = make_double2(1.0, 0.0);
+      if (post && lane == 0) *reinterpret_cast<double2 *>(bo + 2 * (M - 1)) = make_double2(-1.0, 0.0);
+    }
     double acc[2][RS2_ROW];
 #pragma unroll
     for (int c = 0; c < 2; c++)
