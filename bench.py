@@ -159,15 +159,20 @@ def measured_traffic(wl, nel, world, args):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*/traffic.json,
     FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs of this same command and corrected
     as MI355X_MICROARCH.md prescribes).  None when this exact configuration was not profiled."""
-    if world != 1 or args.perturb or args.uniform_material or args.k_only or args.fast_level != 2:
+    if world != 1 or args.uniform_material or args.k_only or args.fast_level != 2:
         return None
+    if wl == "enriched3d" and args.n_enr != 1:
+        return None
+    variant = ("general" if args.perturb else "manufactured" if args.manufactured_loads else
+               "mfma" if (wl == "enriched3d" and args.enr_contraction == "mfma") else "default")
     best = None
     pdir = os.path.join(ROOT, "profiles")
-    for rnd in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+    for rnd in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:  # the latest round that profiled it wins
         f = os.path.join(pdir, rnd, "traffic.json")
         if os.path.exists(f):
             for rec in json.load(open(f)).get("kernels", []):
-                if rec.get("workload") == wl and rec.get("nel") == nel:
+                if (rec.get("workload") == wl and rec.get("nel") == nel
+                        and rec.get("variant", "default") == variant):
                     best = rec.get("hbm_bytes_per_launch")
     return best
 
