@@ -31,8 +31,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="elastic3d", choices=["elastic3d", "poisson3d", "elastic2d", "enriched3d"])
     ap.add_argument("--n-enr", type=int, default=1, help="enriched3d: enrichment families per node (dof = 3(1+n_enr))")
-    ap.add_argument("--enr-contraction", default="default", choices=["default", "valu", "mfma"],
-                    help="enriched3d: local B^T D B contraction on FP64 VALU or v_mfma_f64_16x16x4 (n_enr = 1)")
+    ap.add_argument("--enr-contraction", default="default", choices=["default", "node", "valu", "mfma"],
+                    help="enriched3d: node-centric single pass (default), or element matrices contracted on the FP64 VALU / "
+                         "v_mfma_f64_16x16x4 (n_enr = 1) followed by the segmented reduction")
     ap.add_argument("--nel", type=int, default=0, help="elements per direction (default: 128 / 256 / 2048)")
     ap.add_argument("--perturb", action="store_true", help="general (non-affine) geometry variant")
     ap.add_argument("--uniform-material", action="store_true", help="uniform E,nu instead of the AoS array")
@@ -164,7 +165,7 @@ def measured_traffic(wl, nel, world, args):
     if wl == "enriched3d" and args.n_enr != 1:
         return None
     variant = ("general" if args.perturb else "manufactured" if args.manufactured_loads else
-               "mfma" if (wl == "enriched3d" and args.enr_contraction == "mfma") else "default")
+               args.enr_contraction if (wl == "enriched3d" and args.enr_contraction in ("mfma", "valu")) else "default")
     best = None
     pdir = os.path.join(ROOT, "profiles")
     for rnd in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:  # the latest round that profiled it wins
@@ -245,7 +246,7 @@ def main():
     plan.set_fast_path(args.fast_level)
     if wl == "enriched3d":
         if args.enr_contraction != "default":
-            plan.set_enriched_contraction(1 if args.enr_contraction == "mfma" else 0)
+            plan.set_enriched_contraction({"valu": 0, "mfma": 1, "node": 2}[args.enr_contraction])
         material = synth.props_enriched(M, N, P, coords, n_enr=args.n_enr, e0=els, e1=ele, ck0=cks, E=E, nu=nu)
     elif wl != "poisson3d" and not args.uniform_material and not args.manufactured_loads:
         # the drivers' GaussPointCoefficients fill (S3:1243-1363 / E2:618-670), on device (row N1)
@@ -359,8 +360,9 @@ def main():
             achieved = None
         level = plan.fast_path()
         if wl == "enriched3d":
-            mode = args.enr_contraction if args.enr_contraction != "default" else "valu"
-            kernel = f"k_enr_elem<S={1 + args.n_enr},{mode}> + k_enr_gather (all of K)"
+            mode = args.enr_contraction if args.enr_contraction != "default" else "node"
+            kernel = (f"k_enr_node<S={1 + args.n_enr}>" if mode == "node" else
+                      f"k_enr_elem<S={1 + args.n_enr},{mode}> + k_enr_gather (all of K)")
         elif wl == "elastic2d":
             kernel = "k_assemble_e2_rect" if level == 2 else "k_assemble_rows<PLANE_STRAIN2D>"
         else:

@@ -143,10 +143,13 @@ int femasm_plan_set_stream(femasm_plan *plan, void *stream);
  * levels differ by rounding only. */
 int femasm_plan_set_fast_path(femasm_plan *plan, int level);
 int femasm_plan_get_fast_path(femasm_plan *plan, int *level);
-/* No counterpart in the reference.  FEMASM_ELASTIC3D_ENRICHED: how the local B^T D B contraction of the enriched
- * blocks is done: 0 = FP64 VALU, 1 = v_mfma_f64_16x16x4 (n_enr = 1: the 16 scalar shape functions of an element are
- * one MFMA tile), -1 = the default (the faster one as measured on MI355X).  Results differ by
- * rounding only. */
+/* No counterpart in the reference.  FEMASM_ELASTIC3D_ENRICHED: how the enriched blocks are assembled.
+ *   2 (= -1, the default)  one node-centric pass: a wave owns a node, contracts the blocks of the eight elements
+ *                          around it on the FP64 VALU and writes the node's CSR block; no scratch memory
+ *   0 / 1                  element matrices first (local B^T D B contraction on the FP64 VALU / on
+ *                          v_mfma_f64_16x16x4, n_enr = 1: the 16 scalar shape functions of an element are one MFMA
+ *                          tile) into a scratch ring, then a deterministic segmented reduction per node
+ * Measured on MI355X in DESIGN.md section 9.  Results differ by rounding only. */
 int femasm_plan_set_enriched_contraction(femasm_plan *plan, int mode);
 
 /* Sparsity pattern of the owned rows (A12): rowptr is local (starts at 0, int64 so

@@ -559,6 +559,13 @@ void launch_enr_elem(femasm_plan *p, const EnrArgs &a, int64_t nelem, bool mfma)
   hipLaunchKernelGGL((k_enr_elem<S, false>), grid, dim3(64 * NW), 0, p->stream, p->s, a);
 }
 
+template <int S>
+void launch_enr_node(femasm_plan *p, const EnrArgs &a, int64_t nnodes) {
+  constexpr int per_wg = EnrNodeCfg<S>::NW * EnrNodeCfg<S>::NPW;
+  const dim3 grid((unsigned)((nnodes + per_wg - 1) / per_wg));
+  hipLaunchKernelGGL((k_enr_node<S>), grid, dim3(64 * EnrNodeCfg<S>::NW), 0, p->stream, p->s, a);
+}
+
 int assemble_enriched(femasm_plan *p, const femasm_material *mat, int bc, double *csr_values, double *b,
                       femasm_stats *stats) {
   const auto t_begin = std::chrono::steady_clock::now();
@@ -596,13 +603,14 @@ int assemble_enriched(femasm_plan *p, const femasm_material *mat, int bc, double
 
   if (csr_values && nlay > 0) {
     // ring of element layers: as many as the scratch budget holds (FEMASM_ENR_SCRATCH_MB, default 3072), at least 2
+    const bool two_phase = p->enr_mfma == 0 || p->enr_mfma == 1;  // else: one node-centric pass, no ring
     int64_t budget = 3072;
     if (const char *e = getenv("FEMASM_ENR_SCRATCH_MB")) budget = atoll(e) > 0 ? atoll(e) : budget;
     const int64_t layer_doubles = eplane * KE;
     int64_t nring = (budget << 20) / (layer_doubles * 8);
     if (nring > nlay + 1) nring = nlay + 1;
     if (nring < 2) nring = 2;
-    if (nring * layer_doubles > p->ke_ring_count) {
+    if (two_phase && nring * layer_doubles > p->ke_ring_count) {
       if (p->ke_ring) (void)hipFree(p->ke_ring);
       p->ke_ring = nullptr;
       p->ke_ring_count = 0;
@@ -634,7 +642,33 @@ int assemble_enriched(femasm_plan *p, const femasm_material *mat, int bc, double
     };
     if (M * N * (s.ke - s.ks + 1) / ENR_GW >= ((int64_t)1 << 31)) return fail(FEMASM_ERR_ARG, "slab too large for one launch");
     if (stats) HIPCHK(hipEventRecord(p->ev[4], p->stream));
-    for (int64_t L0 = s.els; L0 < s.ele; L0 += chunk) {
+    // default: one node-centric pass (k_enr_node), nothing but the CSR values leaves the chip; the two-kernel
+    // form (element matrices through a scratch ring) is what femasm_plan_set_enriched_contraction(0 | 1) selects
+    auto node_pass = [&](double *out, int64_t l0, int64_t l1, int iface) {
+      if (l1 <= l0) return;
+      EnrArgs g = a;
+      g.out = out;
+      g.s0 = l0;
+      g.s1 = l1;
+      g.iface = iface;
+      g.base_off = iface ? row_start(s, 0, 0, l0, 0) : 0;
+      const int64_t nn = M * N * (l1 - l0);
+      switch (S) {
+        case 1: launch_enr_node<1>(p, g, nn); break;
+        case 2: launch_enr_node<2>(p, g, nn); break;
+        case 3: launch_enr_node<3>(p, g, nn); break;
+        default: launch_enr_node<4>(p, g, nn); break;
+      }
+    };
+    if (!two_phase) {
+      if (s.ks > 0 && p->send) {
+        node_pass(p->sfull, s.ks - 1, s.ks, 1);
+        if (int rcp = launch_iface_pack(p)) return rcp;
+      }
+      node_pass(csr_values, s.ks, s.ke, 0);
+      HIPCHK(hipGetLastError());
+    }
+    for (int64_t L0 = s.els; two_phase && L0 < s.ele; L0 += chunk) {
       const int64_t L1 = (L0 + chunk < s.ele) ? L0 + chunk : s.ele;
       EnrArgs el = a;
       el.L0 = L0;
@@ -1209,7 +1243,8 @@ int femasm_plan_set_fast_path(femasm_plan *p, int level) {
 int femasm_plan_set_enriched_contraction(femasm_plan *p, int mode) {
   if (!p) return fail(FEMASM_ERR_ARG, "null plan");
   if (p->kind != KIND_ENRICHED) return fail(FEMASM_ERR_ARG, "not an enriched plan");
-  if (mode < -1 || mode > 1) return fail(FEMASM_ERR_ARG, "mode %d: -1 default, 0 VALU, 1 FP64 MFMA", mode);
+  if (mode < -1 || mode > 2)
+    return fail(FEMASM_ERR_ARG, "mode %d: -1 default (= 2), 0 element matrices on VALU, 1 on FP64 MFMA, 2 node-centric pass", mode);
   if (mode == 1 && p->n_enr != 1)
     return fail(FEMASM_ERR_ARG, "the FP64 MFMA contraction exists for n_enr = 1 (16 scalar functions = one 16x16x4 tile)");
   p->enr_mfma = mode;

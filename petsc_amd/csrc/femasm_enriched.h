@@ -408,6 +408,331 @@ __global__ __launch_bounds__(64 * ENR_GW) void k_enr_gather(const Slab s, const 
 }
 
 // ---------------------------------------------------------------------------
+// One pass, node-centric: k_enr_node<S>.  The two kernels above move every element matrix through HBM (18 KB out and
+// 18 KB back per element for S = 2: 5.4x the bytes of the CSR values they end up in).  Here one wave owns one node and
+// nothing but the node's CSR block leaves the chip:
+//   phase 1  lane (e, p): element e of the 8 around the node (k -> j -> i order), Gauss point p.  Jacobian, inverse
+//            (reference order), physical gradients of the eight N_b -> T[e][p][b][3]; w detJ scaled (D11, D12, D44),
+//            phi and grad phi of every family, and the gradients of the ROW node's S functions -> U[e][p][..]
+//            (an element outside the mesh or outside the layers this rank assembles gets zero coefficients)
+//   phase 2  lane (e, b): column node b of element e.  All S x S blocks (row family s, column family t) of the pair
+//            (this node, b) over the eight Gauss points: 21 FMAs per block and point, accumulators in registers
+//   phase 3  per row family: registers -> stage[e][b][r][t][c] (aliases T/U, which are dead by then), then eight
+//            conflict-free rounds, one per element in the reference's ADD order, add the 8 x 9 S values of element e into
+//            the node's CSR block in LDS; row rules (Dirichlet faces, blocked redundant dofs); the block is contiguous
+//            in the CSR array and is written 16 B per lane from the 128-byte boundary below it.
+// Each element's geometry is computed by the eight waves of its nodes (8 x 64 Jacobians per node, ~20 % of the
+// arithmetic); in exchange the kernel's HBM traffic is the CSR values plus the (cached) records.
+// Every CSR value has one writer and a fixed order of additions: bitwise reproducible.
+// ---------------------------------------------------------------------------
+template <int S> struct EnrNodeCfg {
+  static constexpr int NE = S - 1, D = 3 * S;
+  static constexpr int SB = (S <= 2) ? S : 1;          // row families per contraction pass (9 S SB accumulators)
+  static constexpr bool ALIAS = (SB == S);             // stage + block reuse the T/U area (single pass only)
+  static constexpr int UW = 3 + 4 * NE + 3 * S;        // coefficients, (phi, grad phi) per family, row gradients
+  static constexpr int UWP = (UW + 1) & ~1;
+  static constexpr int TPS = 25, TES = 8 * TPS;        // T: 25 doubles per Gauss point (24 gradients + the activity flag
+                                                       // of node p), 200 per element: with these strides the 8-byte
+                                                       // accesses of 16 consecutive lanes fall on 16 distinct bank pairs
+                                                       // both when lanes (e, p) write and when lanes (e, b) read
+  static constexpr int UES = 8 * UWP + 2;
+  static constexpr int IN = 8 * TES + 8 * UES;
+  static constexpr int STG = 64 * 9 * S, ACC = 27 * D * D;
+  static constexpr int OUT = (STG + ACC + 1) & ~1;
+  static constexpr int PER_WAVE = ALIAS ? (IN > OUT ? IN : OUT) : IN + OUT;
+  static constexpr int NW = (S <= 2) ? 8 : 2;          // waves per workgroup (LDS: 20 KB per wave for S = 2)
+  static constexpr int NPW = 8;                        // consecutive nodes per wave
+  static constexpr int NV = 72 * S, NIT = (NV + 63) / 64;  // values of one element and row family, rounds of 64 lanes
+};
+
+template <int S>
+__global__ __launch_bounds__(64 * EnrNodeCfg<S>::NW) void k_enr_node(const Slab s, const EnrArgs a) {
+  using Cf = EnrNodeCfg<S>;
+  constexpr int NE = Cf::NE, D = Cf::D, NW = Cf::NW, SB = Cf::SB, TES = Cf::TES, TPS = Cf::TPS, UES = Cf::UES, UWP = Cf::UWP;
+  constexpr int NIT = Cf::NIT, NV = Cf::NV, RO = 3 + 4 * NE;  // RO: row gradients inside a U record
+  __shared__ __attribute__((aligned(16))) double sh_w[NW][Cf::PER_WAVE];
+  __shared__ double sh_G[8][3][8], sh_N[8][8];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int t = tid; t < 192; t += 64 * NW) (&sh_G[0][0][0])[t] = (&c_tab3.G[0][0][0])[t];
+  for (int t = tid; t < 64; t += 64 * NW) (&sh_N[0][0])[t] = (&c_tab3.N[0][0])[t];
+  __syncthreads();  // (the only workgroup barrier)
+  double *T = sh_w[w], *U = T + 8 * TES;
+  // activity flag of node n of element el: the 25th double of its T record of Gauss point n
+  auto act_of = [&](int el, int n) { return reinterpret_cast<int *>(T + el * TES + n * TPS + 24); };
+  double *stg = Cf::ALIAS ? T : U + 8 * UES, *acc = stg + Cf::STG;
+  auto wave_sync = [&]() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  };
+  const int64_t M = s.dim[0], N = s.dim[1], P = s.dim[2];
+  const int64_t mx = M - 1, my = N - 1;
+  const int e = lane >> 3, b = lane & 7;  // phase 1: Gauss point p = b
+  const int ox = (e & 1) - 1, oy = ((e >> 1) & 1) - 1, oz = (e >> 2) - 1;
+  const int arow = 4 * (-oz) + ((-ox) == 0 ? ((-oy) == 0 ? 0 : 1) : ((-oy) == 0 ? 3 : 2));  // hex_idx(-ox, -oy, -oz)
+  const int bI = (b >> 1) & 1, bJ = ((b + 1) >> 1) & 1, bK = b >> 2;  // HDI, HDJ, HDK of the column node
+  // node-independent decode of the reduction rounds: position u = lane + 64 it of an element's 8 x 9 S staged values
+  int rd_r[NIT], rd_tc[NIT], rd_bI[NIT], rd_bJ[NIT], rd_bK[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    const int u = lane + 64 * it, ub = (u < NV ? u : 0) / (9 * S), v = (u < NV ? u : 0) - 9 * S * ub;
+    rd_r[it] = v / (3 * S);
+    rd_tc[it] = v - 3 * S * rd_r[it];
+    rd_bI[it] = (ub >> 1) & 1;
+    rd_bJ[it] = ((ub + 1) >> 1) & 1;
+    rd_bK[it] = ub >> 2;
+  }
+  const int64_t nn = M * N * (a.s1 - a.s0);
+  const int64_t q0 = ((int64_t)blockIdx.x * NW + w) * Cf::NPW;
+#pragma unroll 1
+  for (int64_t q = q0; q < q0 + Cf::NPW && q < nn; q++) {
+    const int64_t i = q % M, j = (q / M) % N, k = a.s0 + q / (M * N);
+    const int cntx = span1(i, M), cnty = span1(j, N), cntz = span1(k, P);
+    const int rowlen = cntx * cnty * cntz * D, nvals = D * rowlen;
+    const int xi0 = (i == 0), yi0 = (j == 0), zi0 = (k == 0);
+    const bool dirichlet = (a.bc == BC_S3) && on_boundary(s, i, j, k);
+
+    // ---- phase 1: lane (e, p) ----
+    const int64_t ex = i + ox, ey = j + oy, ez = k + oz;
+    const bool ok = !(ex < 0 || ex >= mx || ey < 0 || ey >= my || ez < s.els || ez >= s.ele);
+    const int64_t exc = ex < 0 ? 0 : (ex >= mx ? mx - 1 : ex), eyc = ey < 0 ? 0 : (ey >= my ? my - 1 : ey);
+    const int64_t ezc = ez < s.els ? s.els : (ez >= s.ele ? s.ele - 1 : ez);
+    const double *rec = a.gp + (exc + mx * (eyc + my * (ezc - s.mat_e_ks))) * (int64_t)a.stride;
+    int actp = 0;
+    {
+      const int p = b;
+      double xs[24];
+#pragma unroll
+      for (int n = 0; n < 8; n++) {
+        const double *xp = a.coords + 3 * ((exc + HDI[n]) + M * ((eyc + HDJ[n]) + N * (ezc + HDK[n] - s.cks)));
+        xs[3 * n] = xp[0];
+        xs[3 * n + 1] = xp[1];
+        xs[3 * n + 2] = xp[2];
+      }
+      const double Ep = rec[96 + p], nup = rec[104 + p];
+      double psin[NE > 0 ? NE : 1][8], psig[NE > 0 ? NE : 1], dpsi[NE > 0 ? NE : 1][3];
+      if constexpr (NE > 0) {
+        actp = enr_active(rec, a.base, p, NE);
+#pragma unroll
+        for (int m = 0; m < NE; m++) {
+          const double *en = rec + a.base + 64 * m;
+#pragma unroll
+          for (int n = 0; n < 8; n++) psin[m][n] = en[n];
+          psig[m] = en[8 + p];
+#pragma unroll
+          for (int kk = 0; kk < 3; kk++) dpsi[m][kk] = en[16 + 3 * p + kk];
+        }
+        *act_of(e, p) = actp;
+      }
+      double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+      for (int n = 0; n < 8; n++)
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) J[r][c] = J[r][c] + sh_G[p][r][n] * xs[3 * n + c];
+      double iJ[3][3], det;
+      inv3_ref(J, iJ, det);
+      const double wJ = 1.0 * det;
+      // the element is counted once, by the wave of its local node 6 (always an owned node of this rank)
+      if (ok && e == 0 && !a.iface && !(wJ > 0.0)) atomicAdd(a.bad, 1ULL);
+      double gN[8][3];
+      double *Tp = T + e * TES + p * TPS;
+#pragma unroll
+      for (int n = 0; n < 8; n++)
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) {
+          gN[n][kk] = sh_G[p][0][n] * iJ[kk][0] + sh_G[p][1][n] * iJ[kk][1] + sh_G[p][2][n] * iJ[kk][2];
+          Tp[3 * n + kk] = gN[n][kk];
+        }
+      double *Up = U + e * UES + p * UWP;
+      double d11 = 0.0, d12 = 0.0, d44 = 0.0;
+      if (ok) scaled_coefs<KIND_ELASTIC>(Ep, nup, wJ, d11, d12, d44);
+      Up[0] = d11;
+      Up[1] = d12;
+      Up[2] = d44;
+      if constexpr (NE > 0) {
+#pragma unroll
+        for (int m = 0; m < NE; m++) {
+          double phi = psig[m], dphi[3] = {dpsi[m][0], dpsi[m][1], dpsi[m][2]};
+          if (a.sgfem) {
+#pragma unroll
+            for (int n = 0; n < 8; n++) {
+              phi = phi - sh_N[p][n] * psin[m][n];
+#pragma unroll
+              for (int kk = 0; kk < 3; kk++) dphi[kk] = dphi[kk] - gN[n][kk] * psin[m][n];
+            }
+          }
+          Up[3 + 4 * m] = phi;
+#pragma unroll
+          for (int kk = 0; kk < 3; kk++) Up[4 + 4 * m + kk] = dphi[kk];
+        }
+      }
+      wave_sync();  // T and the activity flags of all eight nodes of the element are in LDS
+      const double g0 = Tp[3 * arow], g1 = Tp[3 * arow + 1], g2 = Tp[3 * arow + 2];
+      Up[RO] = g0;
+      Up[RO + 1] = g1;
+      Up[RO + 2] = g2;
+      if constexpr (NE > 0) {
+        const int actr = *act_of(e, arow);
+        const double Nr = sh_N[p][arow];
+#pragma unroll
+        for (int m = 0; m < NE; m++) {
+          const double phi = Up[3 + 4 * m];
+          const bool on = m < actr;
+          Up[RO + 3 * (1 + m)] = on ? phi * g0 + Nr * Up[4 + 4 * m] : 0.0;
+          Up[RO + 3 * (1 + m) + 1] = on ? phi * g1 + Nr * Up[5 + 4 * m] : 0.0;
+          Up[RO + 3 * (1 + m) + 2] = on ? phi * g2 + Nr * Up[6 + 4 * m] : 0.0;
+        }
+      }
+    }
+    wave_sync();
+
+    const int self = (((k > 0) * cnty + (j > 0)) * cntx + (i > 0)) * D;
+    if (!Cf::ALIAS) {
+      for (int t = lane; t < nvals; t += 64) acc[t] = 0.0;
+    }
+    if (!dirichlet) {
+      // lane-side part of the deposit position: (column node of the staged value) x D + column dof + row x rowlen
+      int rd_pos[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; it++)
+        rd_pos[it] = rd_r[it] * rowlen + ((rd_bK[it] * cnty + rd_bJ[it]) * cntx + rd_bI[it]) * D + rd_tc[it];
+#pragma unroll 1
+      for (int s0 = 0; s0 < S; s0 += SB) {
+        // ---- phase 2: lane (e, b), row families [s0, s0 + SB) ----
+        double av[SB][S][9];
+#pragma unroll
+        for (int sa = 0; sa < SB; sa++)
+#pragma unroll
+          for (int t = 0; t < S; t++)
+#pragma unroll
+            for (int v = 0; v < 9; v++) av[sa][t][v] = 0.0;
+#if FEMASM_EXP == 13 || FEMASM_EXP == 14  // profiling build: no contraction
+#pragma unroll 1
+        for (int p = 0; p < 0; p++) {
+#else
+#pragma unroll 2
+        for (int p = 0; p < 8; p++) {
+#endif
+          const double *Tp = T + e * TES + p * TPS + 3 * b;
+          const double *Up = U + e * UES + p * UWP;
+          const double d11 = Up[0], d12 = Up[1], d44 = Up[2];
+          double G[S][3];
+          G[0][0] = Tp[0];
+          G[0][1] = Tp[1];
+          G[0][2] = Tp[2];
+          if constexpr (NE > 0) {
+            const double Nb = sh_N[p][b];
+#pragma unroll
+            for (int m = 0; m < NE; m++) {
+              const bool on = m < actp;
+              const double phi = Up[3 + 4 * m];
+#pragma unroll
+              for (int kk = 0; kk < 3; kk++) G[1 + m][kk] = on ? phi * G[0][kk] + Nb * Up[4 + 4 * m + kk] : 0.0;
+            }
+          }
+#pragma unroll
+          for (int sa = 0; sa < SB; sa++) {
+            const double *R = Up + RO + 3 * (s0 + sa);
+            double l[3], mm[3], qq[3];
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++) {
+              l[kk] = d12 * R[kk];
+              mm[kk] = d44 * R[kk];
+              qq[kk] = d11 * R[kk];
+            }
+#pragma unroll
+            for (int t = 0; t < S; t++) add_block<KIND_ELASTIC, 3>(av[sa][t], l, mm, qq, G[t]);
+          }
+        }
+        // ---- phase 3: stage, then the eight ordered rounds ----
+        wave_sync();  // every lane is done with T and U (which the stage may alias)
+#if FEMASM_EXP == 12 || FEMASM_EXP == 14  // profiling build: no staging, no rounds
+#pragma unroll
+        for (int sa = 0; sa < SB; sa++)
+#pragma unroll
+          for (int t = 0; t < S; t++)
+#pragma unroll
+            for (int v = 0; v < 9; v++) asm volatile("" ::"v"(av[sa][t][v]));
+        continue;
+#endif
+        if (Cf::ALIAS) {
+          for (int t = lane; t < nvals; t += 64) acc[t] = 0.0;
+        }
+#pragma unroll
+        for (int sa = 0; sa < SB; sa++) {
+          if (sa > 0) wave_sync();  // the rounds of the previous family have read the stage
+#pragma unroll
+          for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int t = 0; t < S; t++)
+#pragma unroll
+              for (int c = 0; c < 3; c++) stg[lane * (9 * S) + r * (3 * S) + 3 * t + c] = av[sa][t][3 * r + c];
+          wave_sync();
+          const int rowbase = 3 * (s0 + sa) * rowlen;
+#pragma unroll
+          for (int e8 = 0; e8 < 8; e8++) {
+            const int x8 = (e8 & 1) - 1, y8 = ((e8 >> 1) & 1) - 1, z8 = (e8 >> 2) - 1;
+            const int64_t fx = i + x8, fy = j + y8, fz = k + z8;
+            if (fx < 0 || fx >= mx || fy < 0 || fy >= my || fz < s.els || fz >= s.ele) continue;  // (wave-uniform)
+            const int epart = (((z8 + 1 - zi0) * cnty + (y8 + 1 - yi0)) * cntx + (x8 + 1 - xi0)) * D + rowbase;
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+              const int u = lane + 64 * it;
+              if (u < NV) {
+                const int pos = epart + rd_pos[it];
+                acc[pos] = acc[pos] + stg[e8 * NV + u];
+              }
+            }
+            wave_sync();  // the next element's read-modify-writes come after these
+          }
+        }
+      }
+    } else if (Cf::ALIAS) {
+      for (int t = lane; t < nvals; t += 64) acc[t] = 0.0;
+    }
+    wave_sync();
+    // ---- row rules: Dirichlet faces (all dofs of the node), blocked redundant dofs ----
+    {
+      int nact = NE;
+      if (!dirichlet && NE > 0 && !a.iface) {
+        const int64_t bx = i > 0 ? i - 1 : 0, by = j > 0 ? j - 1 : 0, bz = k > 0 ? k - 1 : 0;  // the element behind the node
+        const double *rb = a.gp + (bx + mx * (by + my * (bz - s.mat_e_ks))) * (int64_t)a.stride;
+        nact = enr_active(rb, a.base, hex_idx(i > 0, j > 0, k > 0), NE);
+      }
+      const double diag = a.iface ? 0.0 : 1.0;
+      const int qfirst = dirichlet ? 0 : 3 * (1 + nact);  // rows [qfirst, D) become unit rows
+      if (dirichlet || !a.iface) {
+        for (int qr = qfirst; qr < D; qr++)
+          for (int t = lane; t < rowlen; t += 64) acc[qr * rowlen + t] = (t == self + qr) ? diag : 0.0;
+      }
+    }
+    wave_sync();
+    // ---- the block -> CSR array, 16 B per lane from the 128-byte boundary below it ----
+    {
+      double *o = a.out + (row_start(s, i, j, k, 0) - a.base_off);
+      const int head = (int)((reinterpret_cast<uintptr_t>(o) >> 3) & 15);
+      for (int t0 = -head; t0 < nvals; t0 += 128) {
+        const int t = t0 + 2 * lane;
+        if (t >= 0 && t + 1 < nvals) {
+          const double v0 = acc[t], v1 = acc[t + 1];
+#if FEMASM_EXP == 11 || FEMASM_EXP == 14  // profiling build: no global stores
+          asm volatile("" ::"v"(v0), "v"(v1));
+          continue;
+#endif
+          *reinterpret_cast<double2 *>(o + t) = make_double2(v0, v1);
+        } else if (t + 1 >= 0 && t + 1 < nvals && t < 0) {
+          o[t + 1] = acc[t + 1];
+        } else if (t >= 0 && t < nvals) {
+          o[t] = acc[t];
+        }
+      }
+    }
+    wave_sync();  // the next node's phase 1 overwrites the block
+  }
+}
+
+// ---------------------------------------------------------------------------
 // RHS of the enriched element (S3:520-656 with Phi_{a,s} in place of N_a): one thread per element -> element
 // vectors (blocks of 16 elements x 8 D lines, as ef_idx), then one thread per node.
 // ---------------------------------------------------------------------------

@@ -28,7 +28,8 @@
 //   5  the b stores of the one-pass k_assemble_e2_rect<true>
 //   6  a 9-FMA stand-in for the 15-FMA isotropic block of add_block (numbers are wrong: timing only)
 //   7  the record stores of k_rhs_elem_elastic_runs;  8  also its arithmetic (input stream + LDS commit only)
-// femasm_enriched.h: 1 removes the ring stores of k_enr_elem (the VALU-versus-MFMA contraction-only timing).
+// femasm_enriched.h: 1 removes the ring stores of k_enr_elem (the VALU-versus-MFMA contraction-only timing);
+//   k_enr_node: 11 no global stores, 12 no staging/rounds, 13 no contraction, 14 all three (phase 1 + block zero/read)
 #ifndef FEMASM_EXP
 #define FEMASM_EXP 0
 #endif

@@ -189,7 +189,8 @@ class Plan:
         return out.reshape(self.nel, nr, nr)
 
     def set_enriched_contraction(self, mode):
-        """-1 default, 0 FP64 VALU, 1 FP64 MFMA (n_enr = 1)."""
+        """-1 default (= 2), 0 / 1: element matrices on the FP64 VALU / FP64 MFMA (n_enr = 1) + segmented reduction,
+        2: one node-centric pass."""
         _check(load().femasm_plan_set_enriched_contraction(self._h, C.c_int(int(mode))))
 
     def assemble_system(self, values, b, material=None, bc=BC_NONE, E=0.0, nu=0.0, stride=0, e_ks=None,

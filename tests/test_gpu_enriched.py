@@ -76,7 +76,10 @@ def gpu_assemble(env, case, mode=-1, ks=0, ke=None):
 
 
 @pytest.mark.parametrize("dims,n_enr,mode", [((4, 4, 4), 1, 0), ((4, 4, 4), 1, 1), ((6, 5, 7), 1, 0), ((6, 5, 7), 1, 1),
-                                             ((5, 4, 4), 2, 0), ((4, 3, 5), 3, 0), ((2, 2, 2), 1, 1), ((9, 3, 4), 0, 0)])
+                                             ((5, 4, 4), 2, 0), ((4, 3, 5), 3, 0), ((2, 2, 2), 1, 1), ((9, 3, 4), 0, 0),
+                                             # mode 2: the node-centric single pass (the default)
+                                             ((4, 4, 4), 1, 2), ((6, 5, 7), 1, 2), ((5, 4, 4), 2, 2), ((4, 3, 5), 3, 2),
+                                             ((2, 2, 2), 1, 2), ((9, 3, 4), 0, 2), ((11, 3, 2), 1, 2), ((3, 10, 3), 2, 2)])
 @pytest.mark.parametrize("perturb", [False, True])
 def test_enriched_system_matches_the_restatement(env, dims, n_enr, mode, perturb):
     case = make_case(env, dims, n_enr, perturb=perturb)
@@ -89,7 +92,7 @@ def test_enriched_system_matches_the_restatement(env, dims, n_enr, mode, perturb
     plan.close()
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("sgfem,base,dirichlet", [(1, 416, True), (0, 408, True), (1, 408, False), (0, 416, False)])
 def test_partial_enrichment_gfem_and_64bit_flags(env, mode, sgfem, base, dirichlet):
     """families active at some nodes only (blocked redundant dofs elsewhere), GFEM / SGFEM, 32- and 64-bit PetscInt"""
@@ -98,7 +101,7 @@ def test_partial_enrichment_gfem_and_64bit_flags(env, mode, sgfem, base, dirichl
     assert rel(vals, case["K"]) <= TOL and rel(b, case["b"]) <= TOL
     plan.close()
     case2 = make_case(env, (5, 4, 4), 2, sgfem=sgfem, base=base, partial=True, dirichlet=dirichlet, seed=11)
-    plan, vals, b = gpu_assemble(env, case2, 0)
+    plan, vals, b = gpu_assemble(env, case2, 2 if mode == 2 else 0)
     assert rel(vals, case2["K"]) <= TOL and rel(b, case2["b"]) <= TOL
     plan.close()
 
@@ -134,7 +137,7 @@ def test_nothing_enriched_is_config4(env, perturb):
     # n_enr = 1, nothing active: displacement sub-system == config 4, enriched rows = unit rows, b = 0 there
     et = np.zeros((P, N, M), dtype=np.int64)
     props = O.props_enriched(M - 1, N - 1, P - 1, coords, 1, PSI[:1], etype=et, nenrich=et)
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         p1 = F.Plan(F.ELASTIC3D_ENRICHED, M, N, P, coords=torch.from_numpy(coords).to(dev), n_enr=1)
         p1.set_enriched_contraction(mode)
         v1 = torch.empty(p1.nnz, dtype=torch.float64, device=dev)
@@ -161,7 +164,7 @@ def test_nothing_enriched_is_config4(env, perturb):
 def test_raw_enriched_operator_is_symmetric_with_translations_in_its_kernel(env):
     """patch / rigid-body test on the assembled matrix (no Dirichlet rows, every node enriched)"""
     case = make_case(env, (5, 5, 4), 1, dirichlet=False, vary=True)
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         plan, vals, _ = gpu_assemble(env, case, mode)
         rp, ci = plan.pattern()
         plan.close()
@@ -184,12 +187,17 @@ def test_valu_and_mfma_contractions_agree_and_repeat_bitwise(env):
     p2, v2, b2 = gpu_assemble(env, case, 1)
     assert rel(v0, v1) <= TOL and np.array_equal(b0, b1)
     assert np.array_equal(v1, v2) and np.array_equal(b1, b2)
-    for p in (p0, p1, p2):
+    p3, v3, b3 = gpu_assemble(env, case, 2)      # the node-centric pass: same terms, another order of additions
+    p4, v4, b4 = gpu_assemble(env, case, -1)     # ... which is the default
+    assert rel(v0, v3) <= TOL and np.array_equal(b0, b3)
+    assert np.array_equal(v3, v4) and np.array_equal(b3, b4)
+    for p in (p0, p1, p2, p3, p4):
         p.close()
 
 
+@pytest.mark.parametrize("mode", [0, 2])
 @pytest.mark.parametrize("nslab", [2, 3])
-def test_enriched_slabs_plus_interface_equal_the_global_system(env, nslab):
+def test_enriched_slabs_plus_interface_equal_the_global_system(env, nslab, mode):
     torch, F, dev, slab = env["torch"], env["F"], env["dev"], env["slab"]
     case = make_case(env, (5, 4, 9), 1, partial=False)
     M, N, P = case["dims"]
@@ -202,6 +210,7 @@ def test_enriched_slabs_plus_interface_equal_the_global_system(env, nslab):
         els, ele = slab.element_range(ks, ke)
         co = torch.from_numpy(case["coords"].reshape(P, -1)[cks:cke].reshape(-1).copy()).to(dev)
         plan = F.Plan(F.ELASTIC3D_ENRICHED, M, N, P, coords=co, ks=ks, ke=ke, cks=cks, cke=cke, n_enr=1)
+        plan.set_enriched_contraction(mode)
         mat = torch.from_numpy(case["props"].reshape(-1, plane_e * stride)[els:ele].reshape(-1).copy()).to(dev)
         vals = torch.full((plan.nnz,), float("nan"), dtype=torch.float64, device=dev)
         b = torch.full((plan.nrows,), float("nan"), dtype=torch.float64, device=dev)
