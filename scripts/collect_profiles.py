@@ -17,8 +17,10 @@ DOM = {
     "elastic3d_general": ("elastic3d", "general", ["k_assemble_sweep<2>"], "k_assemble_sweep<ELASTIC3D>", 128),
     "poisson3d_general": ("poisson3d", "general", ["k_assemble_sweep_p3"], "k_assemble_sweep<POISSON3D>", 256),
     "elastic2d_general": ("elastic2d", "general", ["k_assemble_rows<1>"], "k_assemble_rows<PLANE_STRAIN2D>", 2048),
-    # all of K = element matrices + segmented reduction: bytes per launch PAIR times the launch pairs of a step
-    "enriched3d": ("enriched3d", "default", ["k_enr_elem<2; false>", "k_enr_gather<6>"], "k_enr_elem + k_enr_gather", 128),
+    "enriched3d": ("enriched3d", "default", ["k_enr_node<2>"], "k_enr_node<S=2>", 128),
+    # the two-kernel form: all of K = element matrices + segmented reduction, bytes per launch PAIR times the launch
+    # pairs of a step
+    "enriched3d_valu": ("enriched3d", "valu", ["k_enr_elem<2; false>", "k_enr_gather<6>"], "k_enr_elem + k_enr_gather", 128),
     "enriched3d_mfma": ("enriched3d", "mfma", ["k_enr_elem<2; true>", "k_enr_gather<6>"], "k_enr_elem + k_enr_gather", 128),
 }
 kernels = []
