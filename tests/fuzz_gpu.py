@@ -3,7 +3,8 @@
     python tests/fuzz_gpu.py --seconds 120 --seed 1
 
 Random problem kind, mesh extents around the kernels' tile sizes, mesh type (uniform / graded rectilinear / sheared /
-perturbed), material (constant / one (E,nu) per element / per Gauss point), slab count and the split interface call;
+perturbed), material (constant / one (E,nu) per element / per Gauss point), slab count, the split interface call, the
+asynchronous mode, and (--kinds enr) the enriched kind with random families, flags, record width and assembly form;
 every system is compared with the CPU oracle at the tolerance of test_gpu_parity.py.  Prints one line per case and
 stops at the first mismatch with the parameters that reproduce it."""
 import argparse
@@ -19,7 +20,7 @@ sys.path.insert(0, ROOT)
 TOL = 1e-13
 XS = [2, 3, 4, 5, 9, 16, 17, 21, 22, 23, 31, 32, 33, 34, 43, 63, 64, 65, 66, 67, 85, 97, 127, 128, 129, 130, 131]
 YS = [2, 3, 4, 5, 6, 7, 8, 9, 15, 16, 17, 31, 32, 33, 34, 35, 65, 66]
-BUDGET = {"p3": 60000, "e2": 60000, "s3": 9000}  # elements per case: keeps the serial oracle to a few seconds
+BUDGET = {"p3": 60000, "e2": 60000, "s3": 9000, "enr": 1500}  # elements per case: keeps the serial oracle to a few seconds
 
 
 def rel(a, b):
@@ -77,6 +78,34 @@ def make_case(O, F, rng, kind, dims, mesh, material):
         O.bc_e2(M, N, rp, ci, K, b)
         return dict(problem=F.PLANE_STRAIN2D_Q1, dims=(M, N, 1), coords=coords, props=props, stride=24,
                     bc=F.BC_E2_COMPRESSION, rp=rp, ci=ci, K=K, b=b, nsd=2)
+    if kind == "enr":
+        # the enriched kind (specification of this engine) against its CPU restatement
+        M, N, P = dims
+        n_enr, sgfem, base = int(rng.integers(0, 4)), int(rng.integers(0, 2)), int(rng.choice([408, 416]))
+        dirichlet = bool(rng.integers(0, 2))
+        coords = make_coords(O, rng, 3, M, N, P, mesh)
+        psi = [lambda x, y, z: (x * x + 0.5 * y * z + 0.25 * z, 2 * x, 0.5 * z, 0.5 * y + 0.25),
+               lambda x, y, z: (np.sin(2 * x) * y, 2 * np.cos(2 * x) * y, np.sin(2 * x), 0 * x),
+               lambda x, y, z: (z * z * x + y, z * z, 1 + 0 * x, 2 * z * x)][:n_enr]
+        et = ne = None
+        if n_enr and rng.integers(0, 2):
+            et = (rng.uniform(size=(P, N, M)) < 0.6).astype(np.int64) * rng.integers(1, 4, size=(P, N, M))
+            ne = rng.integers(0, n_enr + 1, size=(P, N, M)).astype(np.int64)
+        props = O.props_enriched(M - 1, N - 1, P - 1, coords, n_enr, psi, etype=et, nenrich=ne, base=base)
+        stride = O.enr_stride(n_enr, base)
+        if material != "constant":
+            pr = props.reshape(-1, stride)
+            w = 1 if material == "element" else 8
+            pr[:, 96:104] = rng.uniform(50, 150, size=(pr.shape[0], w))
+            pr[:, 104:112] = rng.uniform(0.1, 0.4, size=(pr.shape[0], w))
+        D = 3 * (1 + n_enr)
+        rp, ci = O.pattern(3, D, M, N, P)
+        K, b = O.assemble_enriched3d(M, N, P, coords, props, rp, ci, n_enr, sgfem=sgfem, base=base)
+        O.bc_enriched3d(M, N, P, coords, props, rp, ci, K, b, n_enr, dirichlet=dirichlet, base=base)
+        mode = int(rng.choice([0, 2, 2] + ([1] if n_enr == 1 else [])))
+        return dict(problem=F.ELASTIC3D_ENRICHED, dims=(M, N, P), coords=coords, props=props, stride=stride,
+                    bc=F.BC_S3_ALLFACES_EXACT if dirichlet else F.BC_NONE, rp=rp, ci=ci, K=K, b=b, nsd=3,
+                    n_enr=n_enr, enr_mode=0 if sgfem else 1, contraction=mode)
     M, N, P = dims
     coords = make_coords(O, rng, 3, M, N, P, mesh)
     rp, ci = O.pattern(3, 3, M, N, P)
@@ -96,7 +125,7 @@ def make_case(O, F, rng, kind, dims, mesh, material):
                 bc=F.BC_S3_ALLFACES_EXACT, rp=rp, ci=ci, K=K, b=b, nsd=3)
 
 
-def run_slabs(torch, F, slab, dev, case, nslab, split):
+def run_slabs(torch, F, slab, dev, case, nslab, split, use_async=False):
     M, N, P = case["dims"]
     nsd = case["nsd"]
     SL = P if nsd == 3 else N
@@ -107,7 +136,13 @@ def run_slabs(torch, F, slab, dev, case, nslab, split):
         cks, cke = max(ks - 1, 0), min(ke + 1, SL)
         els, ele = slab.element_range(ks, ke)
         co = torch.from_numpy(case["coords"].reshape(SL, -1)[cks:cke].reshape(-1).copy()).to(dev)
-        plan = F.Plan(case["problem"], M, N, P, coords=co, ks=ks, ke=ke, cks=cks, cke=cke)
+        plan = F.Plan(case["problem"], M, N, P, coords=co, ks=ks, ke=ke, cks=cks, cke=cke, n_enr=case.get("n_enr", 0))
+        enr = case["problem"] == F.ELASTIC3D_ENRICHED
+        if enr:
+            plan.set_enriched_contraction(case["contraction"])
+        elif use_async:
+            plan.set_async(1)
+        kw = dict(enr_mode=case["enr_mode"]) if enr else {}
         mat = None
         if case["props"] is not None:
             mat = torch.from_numpy(case["props"].reshape(-1, plane_e * case["stride"])[els:ele].reshape(-1).copy()).to(dev)
@@ -118,11 +153,16 @@ def run_slabs(torch, F, slab, dev, case, nslab, split):
         recv = torch.full((max(rc, 1),), float("nan"), dtype=torch.float64, device=dev)
         if nslab > 1:
             plan.interface_set_buffers(send if sc else None, recv if rc else None)
-        if split and nslab > 1:
+        split_here = split and nslab > 1 and not enr   # (the enriched kind has no split call)
+        if split_here:
             plan.assemble_interface(material=mat, stride=case["stride"], bc=case["bc"], e_ks=els)
+            if use_async:
+                plan.sync()
             sent = send.clone()
-        plan.assemble_system(vals, b, material=mat, stride=case["stride"], bc=case["bc"], e_ks=els)
-        if split and nslab > 1 and sc:
+        plan.assemble_system(vals, b, material=mat, stride=case["stride"], bc=case["bc"], e_ks=els, **kw)
+        if use_async and not enr:
+            plan.sync()
+        if split_here and sc:
             assert torch.equal(sent[:sc], send[:sc]), "the full call changed the send buffer"
         levels.append(plan.fast_path())
         plans.append(plan); outs.append((vals, b)); bufs.append((send, recv, sc, rc))
@@ -132,6 +172,8 @@ def run_slabs(torch, F, slab, dev, case, nslab, split):
     if nslab > 1:
         for r in range(nslab):
             plans[r].interface_apply(outs[r][0], outs[r][1], bc=case["bc"])
+            if use_async and case["problem"] != F.ELASTIC3D_ENRICHED:
+                plans[r].sync()
     K = np.concatenate([o[0].cpu().numpy() for o in outs])
     b = np.concatenate([o[1].cpu().numpy() for o in outs])
     for p in plans:
@@ -164,6 +206,9 @@ def main():
             if kind == "e2":
                 dims = (int(rng.choice(XS + [257, 513])), int(rng.choice(YS + [97, 130])))
                 nel = (dims[0] - 1) * (dims[1] - 1)
+            elif kind == "enr":
+                dims = (int(rng.choice([2, 3, 4, 5, 9, 10, 17])), int(rng.choice([2, 3, 4, 5, 8, 9])), int(rng.choice([2, 3, 4, 5, 7, 9, 12])))
+                nel = (dims[0] - 1) * (dims[1] - 1) * (dims[2] - 1)
             else:
                 dims = (int(rng.choice(XS)), int(rng.choice(YS)), int(rng.choice(YS + [70])))
                 nel = (dims[0] - 1) * (dims[1] - 1) * (dims[2] - 1)
@@ -171,6 +216,9 @@ def main():
                 break
         mesh = str(rng.choice(["uniform", "graded", "graded", "sheared", "perturbed"]))
         material = "none" if kind == "p3" else str(rng.choice(["constant", "element", "element", "gp"]))
+        if kind == "enr" and mesh in ("graded", "sheared"):
+            mesh = "perturbed"
+        use_async = bool(rng.integers(0, 2))
         SL = dims[-1]
         nslab = int(rng.integers(1, min(4, SL // 2) + 1)) if SL >= 4 else 1
         split = bool(rng.integers(0, 2))
@@ -178,9 +226,11 @@ def main():
             if SL < 4:
                 continue
             nslab, split = max(nslab, 2), True
-        tag = f"seed={args.seed} case={n} {kind} dims={dims} mesh={mesh} material={material} nslab={nslab} split={split}"
+        tag = f"seed={args.seed} case={n} {kind} dims={dims} mesh={mesh} material={material} nslab={nslab} split={split} async={use_async}"
         case = make_case(O, F, rng, kind, dims, mesh, material)
-        K, b, levels = run_slabs(torch, F, slab, dev, case, nslab, split)
+        if kind == "enr":
+            tag += f" n_enr={case['n_enr']} enr_mode={case['enr_mode']} contraction={case['contraction']} stride={case['stride']} bc={case['bc']}"
+        K, b, levels = run_slabs(torch, F, slab, dev, case, nslab, split, use_async)
         eK, eb = rel(K, case["K"]), rel(b, case["b"])
         ok = (not np.isnan(K).any()) and (not np.isnan(b).any()) and eK <= TOL and eb <= TOL
         worst = max(worst, eK, eb)
