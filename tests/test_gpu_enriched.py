@@ -245,6 +245,19 @@ def test_small_scratch_ring_gives_the_same_matrix(env, monkeypatch):
     assert rel(v1, case["K"]) <= TOL
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_enriched_inverted_element_is_reported(env, mode):
+    torch, F, O, dev = env["torch"], env["F"], env["O"], env["dev"]
+    case = make_case(env, (6, 5, 5), 1, perturb=False)
+    M, N, P = case["dims"]
+    coords = case["coords"].reshape(-1, 3).copy()
+    coords[2 + M * (2 + N * 2)] = coords[4 + M * (2 + N * 2)] + np.array([0.01, 0.0, 0.0])   # pushed past its neighbour
+    bad = dict(case, coords=coords.reshape(-1))
+    with pytest.raises(F.FemasmError) as ei:
+        gpu_assemble(env, bad, mode)
+    assert ei.value.code == 3 and "det(J)" in str(ei.value)
+
+
 def test_enriched_argument_errors(env):
     torch, F, O, dev = env["torch"], env["F"], env["O"], env["dev"]
     M = 3

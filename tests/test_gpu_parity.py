@@ -467,6 +467,33 @@ def test_results_are_bitwise_reproducible(env):
     p1.close(); p2.close()
 
 
+@pytest.mark.parametrize("kind", ["e2", "s3"])
+def test_inverted_element_is_reported_by_the_elastic_kinds(env, kind):
+    """det J <= 0 at a Gauss point -> FEMASM_ERR_GEOMETRY after the call, on the general kernels the distorted mesh
+    falls back to (the level-2 premise fails first) and when level 0 is set up front"""
+    torch, F, dev, O = env["torch"], env["F"], env["dev"], env["O"]
+    for level in (2, 0):
+        if kind == "e2":
+            M, N = 9, 7
+            coords = O.uniform_coords(2, M, N).reshape(-1, 2)
+            coords[3 + M * 3] = coords[5 + M * 3] + np.array([0.01, 0.0])   # a node pushed past its right-hand neighbour
+            plan = F.Plan(F.PLANE_STRAIN2D_Q1, M, N, 1, coords=torch.from_numpy(coords.reshape(-1)).to(dev))
+            props, stride, bc = O.props_e2(M - 1, N - 1, O.uniform_coords(2, M, N)), 24, F.BC_E2_COMPRESSION
+        else:
+            M = N = 6
+            coords = O.uniform_coords(3, M, M, M).reshape(-1, 3)
+            coords[2 + M * (2 + M * 2)] = coords[4 + M * (2 + M * 2)] + np.array([0.01, 0.0, 0.0])
+            plan = F.Plan(F.ELASTIC3D_Q1, M, M, M, coords=torch.from_numpy(coords.reshape(-1)).to(dev))
+            props, stride, bc = O.props_s3(M - 1, M - 1, M - 1, O.uniform_coords(3, M, M, M)), 400, F.BC_S3_ALLFACES_EXACT
+        plan.set_fast_path(level)
+        vals = torch.empty(plan.nnz, dtype=torch.float64, device=dev)
+        b = torch.empty(plan.nrows, dtype=torch.float64, device=dev)
+        with pytest.raises(F.FemasmError) as ei:
+            plan.assemble_system(vals, b, material=torch.from_numpy(props).to(dev), stride=stride, bc=bc)
+        assert ei.value.code == 3 and "det(J)" in str(ei.value)
+        plan.close()
+
+
 def test_inverted_element_is_reported(env):
     torch, F, dev, O = env["torch"], env["F"], env["dev"], env["O"]
     M = 4
