@@ -1,6 +1,6 @@
 #!/bin/bash
 # full-step timing of experiment builds
-for v in "" _exp1 _exp2 _exp3 _exp4 _exp5; do
+for v in "" _exp1 _exp2 _exp3 _exp4 _exp5 _exp7 _exp8; do
   L=$PWD/petsc_amd/csrc/libfemasm$v.so
   [ -f $L ] || continue
   echo -n "variant '$v': "
