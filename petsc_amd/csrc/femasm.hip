@@ -516,7 +516,14 @@ int launch_rhs(femasm_plan *p, const femasm_material *mat, int bc, double *out, 
         if (wg_per_cu[1] < 1) wg_per_cu[1] = 1;
         if (getenv("FEMASM_DEBUG")) fprintf(stderr, "[femasm] rhs runs: ncu %d, workgroups per CU %d (general) %d (rect)\n", ncu, wg_per_cu[0], wg_per_cu[1]);
       }
-      auto grid = [&](int v) { const int64_t r = (int64_t)ncu * wg_per_cu[v]; return dim3((unsigned)(ntasks < r ? ntasks : r)); };
+      // FEMASM_RHS_GRID caps the grid (tests: several tasks per persistent wave on small meshes)
+      const char *cap_env = getenv("FEMASM_RHS_GRID");
+      const int64_t grid_cap = cap_env ? atoll(cap_env) : 0;
+      auto grid = [&](int v) {
+        int64_t r = (int64_t)ncu * wg_per_cu[v];
+        if (grid_cap > 0 && grid_cap < r) r = grid_cap;
+        return dim3((unsigned)(ntasks < r ? ntasks : r));
+      };
       if (a.rect) hipLaunchKernelGGL(k_rhs_elem_elastic_runs<true>, grid(1), dim3(64), 0, p->stream, sl, a);
       hipLaunchKernelGGL(k_rhs_elem_elastic_runs<false>, grid(0), dim3(64), 0, p->stream, sl, a);
     }

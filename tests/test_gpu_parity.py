@@ -467,6 +467,28 @@ def test_results_are_bitwise_reproducible(env):
     p1.close(); p2.close()
 
 
+@pytest.mark.parametrize("perturb", [False, True])
+def test_s3_rhs_persistent_waves_walk_several_tasks(env, monkeypatch, perturb):
+    """k_rhs_elem_elastic_runs is launched as one resident set of waves that stride over the (chunk, row, run) tasks;
+    small meshes give every wave one task, so the grid is capped here (FEMASM_RHS_GRID) to make each wave walk many,
+    on the box path and on the general one"""
+    torch, F, dev, O = env["torch"], env["F"], env["dev"], env["O"]
+    M, N, P = 35, 9, 40          # 3 runs x 8 rows x 2 chunks = 48 tasks
+    coords = O.uniform_coords(3, M, N, P)
+    if perturb:
+        coords = O.perturb_coords(coords, 3, M, N, P)
+    props = O.props_s3(M - 1, N - 1, P - 1, coords)
+    rp, ci = O.pattern(3, 3, M, N, P)
+    K, b = O.assemble_elastic3d(M, N, P, coords, props, rp, ci)
+    O.bc_s3(M, N, P, coords, rp, ci, K, b)
+    monkeypatch.setenv("FEMASM_RHS_GRID", "5")
+    plan = F.Plan(F.ELASTIC3D_Q1, M, N, P, coords=torch.from_numpy(coords).to(dev))
+    gb = torch.full((plan.nrows,), float("nan"), dtype=torch.float64, device=dev)
+    plan.assemble_system(None, gb, material=torch.from_numpy(props).to(dev), stride=400, bc=F.BC_S3_ALLFACES_EXACT)
+    plan.close()
+    assert rel(gb.cpu().numpy(), b) <= TOL
+
+
 @pytest.mark.parametrize("kind", ["e2", "s3"])
 def test_inverted_element_is_reported_by_the_elastic_kinds(env, kind):
     """det J <= 0 at a Gauss point -> FEMASM_ERR_GEOMETRY after the call, on the general kernels the distorted mesh
