@@ -351,9 +351,12 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
         // node layers per workgroup.  Row-sweep kernel (2 workgroups per CU resident): of 16 / 32 / 64 the one that
         // fills the last round of resident workgroups best, weighed against the ~2-layer prologue of a workgroup
         // (128^3: 64 -> 512 workgroups = exactly one round, 0.92 ms against 0.94 ms with 32; 96^3: 32 -> 0.47 ms against
-        // 0.70 ms with 64; 160^3: 32).  Autonomous-wave Poisson kernel: 16 (8..16 within 1 %, 32: +5 %, 64: +8 %).
+        // 0.70 ms with 64; 160^3: 32).  Autonomous-wave Poisson kernel: ONE -- every wave is a one-shot unit that
+        // writes a single contiguous run, dispatched in memory order, which is the pattern the memory system takes fastest
+        // (scripts/ubench/fill_roof*.hip: one-shot runs in order 5.7-6.8 TB/s, persistent strided writers 4.5-4.8);
+        // 256^3: 0.62 ms against 0.73 ms with 16 layers per wave (2, 4, 8: 0.71-0.72), 128^3: 0.092 against 0.105.
         // FEMASM_ZC overrides for experiments.
-        int64_t zc = 16;
+        int64_t zc = 1;
         if (!(KIND == KIND_POISSON && rect)) {
           const double resident = 2.0 * p->ncu;
           const double tiles = (double)((b.x1 - b.x0 + TX - 1) / TX) * (double)((b.y1 - b.y0 + TY - 1) / TY);
