@@ -371,6 +371,8 @@ def main():
             kernel = f"k_assemble_rowsweep<{kname}>" if fast else f"k_assemble_sweep<{kname}>"
             if wl == "poisson3d" and level == 2:
                 kernel = "k_assemble_p3_rect"
+            if wl == "elastic3d" and level == 2 and not os.environ.get("FEMASM_S3_ROWSWEEP"):
+                kernel = "k_assemble_s3_unit"
         traffic = measured_traffic(wl, nel, world, args)
         out = {
             "metric": "global assembly elements/sec + achieved HBM GB/s fraction",

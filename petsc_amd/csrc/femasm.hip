@@ -378,6 +378,17 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
           dim3 grid((unsigned)((b.x1 - b.x0 + P3W_TX - 1) / P3W_TX), (unsigned)(b.y1 - b.y0),
                     (unsigned)((z1 - z0 + zc - 1) / zc));
           hipLaunchKernelGGL(k_assemble_p3_rect, grid, dim3(64), 0, p->stream, p->s, az);
+        } else if (KIND == KIND_ELASTIC && rect && !getenv("FEMASM_S3_ROWSWEEP") && b.y1 - b.y0 < 65536 && z1 - z0 < 65536) {
+          // elastic on a rectilinear mesh: one-shot units (one wave = one 8-node run each) in memory order
+          // (FEMASM_S3_ROWSWEEP=1: the persistent row-sweep kernel of round 1, for A/B)
+          // x-consecutive units per wave: as many as leave >= 8192 waves (four rounds of the chip at two waves per SIMD);
+          // at 128^3 a wave walks a whole line (measured: 1 unit 1.09 ms, 4: 1.04, 8: 1.00, 16: 0.91-0.93)
+          const int64_t ux = (b.x1 - b.x0 + SU_TX - 1) / SU_TX, lines = (int64_t)(b.y1 - b.y0) * (z1 - z0);
+          const char *nu_env = getenv("FEMASM_S3_UNITS");
+          az.zc = (int32_t)(nu_env ? std::max(1, atoi(nu_env)) : std::max<int64_t>(1, std::min<int64_t>(ux, ux * lines / 8192)));
+          const int64_t per = (int64_t)az.zc * SU_TX;
+          dim3 grid((unsigned)((b.x1 - b.x0 + per - 1) / per), (unsigned)(b.y1 - b.y0), (unsigned)(z1 - z0));
+          hipLaunchKernelGGL(k_assemble_s3_unit, grid, dim3(64), 0, p->stream, p->s, az);
         } else {
           dim3 grid((unsigned)((b.x1 - b.x0 + TX - 1) / TX), (unsigned)((b.y1 - b.y0 + TY - 1) / TY),
                     (unsigned)((z1 - z0 + zc - 1) / zc));
@@ -915,7 +926,7 @@ int femasm_plan_destroy(femasm_plan *p) {
   {  // phase clocks of the row-sweep kernel (profiling build)
     unsigned long long t[32];
     if (p->bad && hipMemcpy(t, p->bad, sizeof t, hipMemcpyDeviceToHost) == hipSuccess) {
-      fprintf(stderr, "[femasm phases] row waves: n=%llu barrier %llu contract %llu stage %llu store %llu | record wave: n=%llu top %llu commit+load %llu build %llu handshakes %llu\n",
+      fprintf(stderr, "[femasm phases] row waves (s3 unit kernel, sampled waves: units, loads+record, rows, stage reads, stores): n=%llu barrier %llu contract %llu stage %llu store %llu | record wave: n=%llu top %llu commit+load %llu build %llu handshakes %llu\n",
               t[8], t[9], t[10], t[11], t[12], t[16], t[17], t[18], t[19], t[20]);
       fprintf(stderr, "[femasm phases] rhs coop: n=%llu commit %llu request %llu phaseA %llu phaseB %llu\n", t[24], t[25], t[26],
               t[27], t[28]);

@@ -590,6 +590,7 @@ __global__ __launch_bounds__(256, 2) void k_assemble_rows(const Slab s, const KA
     ph_[p] += now_ - ph_t;                                       \
     ph_t = now_;                                                 \
   } while (0)
+#define PH_PIN(x) asm volatile("" ::"v"(x))
 #define PH_FLUSH(base)                                                    \
   if (lane == 0) {                                                        \
     atomicAdd(PH_BUF + (base), ph_n);                                      \
@@ -599,6 +600,7 @@ __global__ __launch_bounds__(256, 2) void k_assemble_rows(const Slab s, const KA
 #define PH_DECL
 #define PH_T(id)
 #define PH_ACC(p, id)
+#define PH_PIN(x)
 #define PH_FLUSH(base)
 #endif
 

@@ -1032,6 +1032,256 @@ __global__ __launch_bounds__(64 * (3 + RowSweep<KIND>::NRW), 2) void k_assemble_
 }
 
 // ---------------------------------------------------------------------------
+// S3 / R3 on a verified rectilinear mesh (level 2), ONE-SHOT UNITS: k_assemble_s3_unit.
+// What the memory system of this part takes fastest is not a set of persistent workgroups that each walk the mesh
+// (4.5-4.8 TB/s for the elastic K kernel's 4.25 GB, which is where k_assemble_rowsweep sits) but short-lived workgroups
+// that each write ONE contiguous block and end, dispatched in memory order (5.7-6.9 TB/s; scripts/ubench/fill_roof*.hip).
+// So: one workgroup = ONE WAVE; a unit = 8 x-consecutive interior nodes of one (j, k) line = one 15.5 KB run of the CSR
+// array; a wave walks KArgs::zc x-consecutive units (one contiguous piece of the array) and ends; the grid is
+// (x pieces, lines, layers) = memory order; no barrier, no polling, nothing carried between units but a prefetch.
+//   lane      (layer AS, node lx, element e = (oy, ox)): ONE of the eight box elements around ONE node.  The lane
+//             builds that element's record itself (two x, two y, two z coordinates and the element's (E, nu), all
+//             eight Gauss points bitwise equal, else bad[1]) with the arithmetic of k_assemble_rowsweep's record wave.
+//   uniform   every lane runs the code of the element whose (+,+,+) corner is the node: with s = the node's corner
+//             signs in the lane's element, R_ab[k][l] = s_k s_l R_a'b'[k][l] for the mirrored pair (a', b'), so the
+//             lane multiplies its six off-diagonal record numbers by +-1 (exact) and indexes its neighbours by
+//             "same side / far side" per axis: 8 neighbours x 3 column dofs = 24 accumulators per dof row.
+//   sum       a neighbour is shared by 1, 2, 4 or 8 of the node's elements: quad DPP adds over (oy, ox), then the two
+//             layers add in place in the stage; a fixed tree, so deterministic (the last bit can differ from the chain
+//             order of k_assemble_rowsweep, which is why the two kernels never share a K).
+//   run       deposit in HBM order in the 15.5 KB stage, then 16 B per lane from the 128-byte boundary below the run
+//   prefetch  the next unit's x edge and (E, nu) are requested right after this unit's record is built and before its
+//             stores (loads and stores retire through one in-order counter: a load issued before a store does not
+//             wait for it); the registers it holds (36) are why the kernel runs at two waves per SIMD.
+// Measured (S3 128^3, 254 016 units): one unit per wave 1.09 ms (phase clocks per unit: loads + record
+// 10.4k, rows 5.2k, stage reads 1.3k, stores until acknowledged 4.5k cycles, ten waves per CU), whole line per wave
+// 0.91 ms against 0.93 ms for k_assemble_rowsweep on the same box; without its stores 0.61 ms (row-sweep: 0.89 ms), so
+// neither kernel is at the store roof: this one is bound by its ~800 vector instructions per unit (records rebuilt by the
+// eight lanes that share an element, 216 instructions of cross-lane sums) at eight waves per CU.  Where it clearly wins
+// is below the headline size: 96^3 0.35 against 0.46 ms, 64^3 0.10 against 0.18 ms, 32^3 0.022 against 0.17 ms (the
+// row-sweep grid has too few workgroups there and a two-layer prologue each).
+// ---------------------------------------------------------------------------
+constexpr int SU_TX = 8;
+#ifndef SU_OCC
+#define SU_OCC 2  // waves per SIMD the register allocation aims at (3: measured slower, the prefetched unit spills)
+#endif
+template <int CTRL>
+__device__ inline double quad_perm(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);  // quad_perm reads a lane of the same quad: always valid
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// row C of the lane's node from the lane's element; stg = stage + node block + self neighbour
+template <int C>
+__device__ inline void unit_row(const double *pd, const double *pe, const double *po, const double *pq, double *stg,
+                                int pz, int py, int px, int e, bool lower, bool live) {
+  constexpr int ia = hex_idx(1, 1, 1);
+  constexpr int C1 = (C + 1) % 3, C2 = (C + 2) % 3;
+  double acc[24];  // [mz][my][mx][cc], m = 0: the neighbour on the node's side of the element, 1: the far side
+#pragma unroll
+  for (int mz = 0; mz <= 1; mz++)
+#pragma unroll
+    for (int my = 0; my <= 1; my++)
+#pragma unroll
+      for (int mx = 0; mx <= 1; mx++) {
+        const double(*R)[3] = d_refR.R[ia][hex_idx(1 - mx, 1 - my, 1 - mz)];
+        const int t = (mz * 2 + my) * 2 + mx;
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+          double v = 0.0;
+          if (cc == C) {
+            v = fma(R[C][C], pd[C], v);
+            v = fma(R[C1][C1], pe[C1], v);
+            v = fma(R[C2][C2], pe[C2], v);
+          } else {
+            v = fma(R[C][cc], po[C + cc - 1], v);
+            v = fma(R[cc][C], pq[C + cc - 1], v);
+          }
+          acc[t * 3 + cc] = v;
+        }
+      }
+  // the elements that share a neighbour: (oy, ox) partners in the quad, then the other layer
+#pragma unroll
+  for (int mz = 0; mz <= 1; mz++)
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) {
+      double &a00 = acc[((mz * 2 + 0) * 2 + 0) * 3 + cc], &a01 = acc[((mz * 2 + 0) * 2 + 1) * 3 + cc];
+      double &a10 = acc[((mz * 2 + 1) * 2 + 0) * 3 + cc];
+      a00 += quad_perm<0xB1>(a00);  // ox partner
+      a00 += quad_perm<0x4E>(a00);  // oy partners
+      a01 += quad_perm<0x4E>(a01);  // far in x, same y: the element across y
+      a10 += quad_perm<0xB1>(a10);  // far in y, same x: the element across x
+    }
+#if SU_OCC > 2
+  // (pinned: the compiler otherwise sinks the last add of every sum into the predicated deposit below and keeps both of
+  // its operands alive until then, which doubles the accumulators' registers)
+#pragma unroll
+  for (int q = 0; q < 24; q++) asm volatile("" : "+v"(acc[q]));
+#endif
+  // deposit: one exec mask per group of owners (a shared neighbour is written by one of the lanes that hold its sum).
+  // The middle third (mz = 0) is the sum of both element layers: the lanes of layer kn-1 write, then the lanes of
+  // layer kn add theirs in place -- LDS executes a wave's accesses in order, so the second sees the first.
+  auto put = [&](double *d, int t, bool add) {
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) d[cc] = add ? d[cc] + acc[t * 3 + cc] : acc[t * 3 + cc];
+  };
+#pragma unroll
+  for (int pass = 0; pass < 3; pass++) {  // 0: far third of both layers, 1: middle third from below, 2: from above
+    const int mz = pass == 0 ? 1 : 0;
+    double *d = stg + C * 81 + (mz ? pz : 0);
+    const bool wz = live && (pass == 0 || (pass == 1) == lower);
+    const bool add = pass == 2;
+    if (wz) put(d + py + px, (mz * 2 + 1) * 2 + 1, add);
+    if (wz && (e & 1) == 0) put(d + py, (mz * 2 + 1) * 2 + 0, add);
+    if (wz && (e & 2) == 0) put(d + px, (mz * 2 + 0) * 2 + 1, add);
+    if (wz && e == 0) put(d, (mz * 2 + 0) * 2 + 0, add);
+    if (pass == 1) asm volatile("" ::: "memory");
+  }
+}
+__global__ __launch_bounds__(64, SU_OCC) void k_assemble_s3_unit(const Slab s, const KArgs a) {
+  using R_ = RowSweep<KIND_ELASTIC>;
+  constexpr int NB = R_::NB, RUN = SU_TX * NB;
+  constexpr int PAD = 16;  // doubles either side of the run: the store loop reads whole 16-byte chunks from a line boundary
+  __shared__ __attribute__((aligned(16))) double sh_all[PAD + RUN + PAD];
+  double *sh_stage = sh_all + PAD;
+  const int lane = threadIdx.x;
+  PH_DECL;
+  const int e = lane & 3, lx = (lane >> 2) & 7, AS = lane >> 5;  // AS = 1: element layer kn-1 (the node on its top face)
+  const int ox = (e & 1) - 1, oy = (e >> 1) - 1;
+  const int64_t M = s.dim[0], N = s.dim[1];
+  const int NU = a.zc;  // x-consecutive units of this wave: their runs are one contiguous piece of the CSR array
+  const int64_t ifirst = a.x0 + (int64_t)blockIdx.x * NU * SU_TX, j = a.y0 + blockIdx.y, kn = a.s0 + blockIdx.z;
+  const int64_t gey = j + oy, L = kn - AS;
+  const bool eok = L >= s.els && L < s.ele;
+  const bool aos = a.mat_layout == 0 && eok;
+  auto zline = [&](int64_t k) {
+    const int64_t kc = k < s.cks ? s.cks : (k > a.cke - 1 ? a.cke - 1 : k);
+    return a.coords[3 * (M * N * (kc - s.cks)) + 2];
+  };
+  // what a unit reads: the x edge of the lane's element and its (E, nu) at the eight Gauss points; issued one unit
+  // ahead, right after the previous unit's record is built (the registers are free again) and before its stores:
+  // gfx9 retires loads and stores in one in-order counter, so a load issued BEFORE a store does not wait for it
+  double xa, xb, m[16];
+  auto load_unit = [&](int64_t i0) {
+    const int nv = (a.x1 - i0 < SU_TX) ? (int)(a.x1 - i0) : SU_TX;
+    const int64_t gex = i0 + (lx < nv ? lx : nv - 1) + ox;
+    xa = a.coords[3 * gex], xb = a.coords[3 * (gex + 1)];
+    if (aos) {
+      const double *mq = a.gp + (gex + (M - 1) * (gey + (N - 1) * (L - s.mat_e_ks))) * a.mat_stride + 96;
+#pragma unroll
+      for (int q = 0; q < 16; q++) m[q] = mq[q];
+    }
+  };
+  if (ifirst < a.x1) load_unit(ifirst);
+  // the y and z edges are those of the whole line (k_check_rectilinear has verified that the three coordinate lines
+  // describe the mesh)
+  const double ya = a.coords[3 * (M * gey) + 1], yb = a.coords[3 * (M * (gey + 1)) + 1];
+  const double za = zline(L), zb = zline(L + 1);
+  const double J1 = 0.5 * (yb - ya), J2 = 0.5 * (zb - za);
+  const double ai1 = 1.0 / J1, ai2 = 1.0 / J2;
+  // corner signs of the node in this element: the mirror that makes it the (+,+,+) corner flips the mixed terms
+  const double sx = ox ? 1.0 : -1.0, sy = oy ? 1.0 : -1.0, sz = AS ? 1.0 : -1.0;
+  const double s01 = sx * sy, s02 = sx * sz, s12 = sy * sz;
+  // far-side neighbour steps in the node block: (dz, dy, dx) -> ((dz+1)*9 + (dy+1)*3 + (dx+1)) * 3 + column dof
+  const int pz = AS ? -27 : 27, py = oy ? -9 : 9, px = ox ? -3 : 3;
+  double *stg = sh_stage + lx * NB + 39;
+  const bool lower = AS == 1;
+  for (int u = 0; u < NU; u++) {
+    const int64_t i0 = ifirst + (int64_t)u * SU_TX;
+    if (i0 >= a.x1) break;
+    const int nvx = (a.x1 - i0 < SU_TX) ? (int)(a.x1 - i0) : SU_TX;
+    const bool live = lx < nvx;
+    double pd[3], pe[3], po[3], pq[3];
+    if (!eok) {
+#pragma unroll
+      for (int q = 0; q < 3; q++) pd[q] = pe[q] = po[q] = pq[q] = 0.0;
+    } else {
+      double mE = a.E, mNu = a.nu;
+      if (aos) {
+        bool same = true;
+#pragma unroll
+        for (int q = 1; q < 8; q++) same = same && m[q] == m[0] && m[8 + q] == m[8];
+        mE = m[0];
+        mNu = same ? m[8] : __builtin_nan("");  // NaN marks "varies inside the element"
+      }
+      // the operations of k_assemble_rowsweep's record wave on a box (same bits per element)
+      const double J0 = 0.5 * (xb - xa);
+      if (live && !(mNu == mNu)) atomicAdd(a.bad + 1, 1ULL);
+      const double wJ = 1.0 * (J0 * J1 * J2);
+      if (live && !(wJ > 0.0)) atomicAdd(a.bad, 1ULL);
+      const double ai[3] = {1.0 / J0, ai1, ai2};
+      double d11, d12, d44;
+      scaled_coefs<KIND_ELASTIC>(mE, mNu, wJ, d11, d12, d44);
+      const double q0 = ai[0] * ai[0], q1 = ai[1] * ai[1], q2 = ai[2] * ai[2];
+      const double q01 = ai[0] * ai[1], q02 = ai[0] * ai[2], q12 = ai[1] * ai[2];
+      pd[0] = d11 * q0, pd[1] = d11 * q1, pd[2] = d11 * q2;
+      pe[0] = d44 * q0, pe[1] = d44 * q1, pe[2] = d44 * q2;
+      po[0] = s01 * (d12 * q01), po[1] = s02 * (d12 * q02), po[2] = s12 * (d12 * q12);
+      pq[0] = s01 * (d44 * q01), pq[1] = s02 * (d44 * q02), pq[2] = s12 * (d44 * q12);
+    }
+    PH_PIN(pd[0] + pq[2]);
+    PH_ACC(0, 1);
+    if (u + 1 < NU && i0 + SU_TX < a.x1) load_unit(i0 + SU_TX);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();  // the previous unit's reads of the stage are done
+    unit_row<0>(pd, pe, po, pq, stg, pz, py, px, e, lower, live);
+    unit_row<1>(pd, pe, po, pq, stg, pz, py, px, e, lower, live);
+    unit_row<2>(pd, pe, po, pq, stg, pz, py, px, e, lower, live);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();  // the run is in the stage, in HBM order
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    PH_ACC(1, 2);
+    const int n = nvx * NB;
+    double *runp = a.out + (row_start(s, i0, j, kn, 0) - a.base_off);
+    const int head = (int)((reinterpret_cast<uintptr_t>(runp) & 127) >> 3);  // doubles above a line boundary
+    constexpr int NIT = (RUN / 2 + 8 + 63) / 64;
+    // chunk q = the q-th 16 bytes from that boundary = stage[2q - head, 2q - head + 1]; whole chunks here, the two
+    // possible half chunks (an odd head, an odd end) after the loop
+    const int s0 = 2 * lane - head;
+    const double *src = sh_stage + s0;
+    double *dstp = runp + s0;
+    constexpr int NH = NIT / 2;  // two halves: 16 chunks in flight would cost 64 registers next to the prefetched unit
+    static_assert(NIT % 2 == 0, "store rounds");
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      double2 v[NH];
+#pragma unroll
+      for (int q = 0; q < NH; q++) {
+        const int it = h * NH + q;
+        int o = 128 * it;
+        if (128 * (it + 1) > RUN + PAD) o = (s0 + o + 2 <= RUN + PAD) ? o : 0;  // last round: stay inside the array
+        v[q] = make_double2(src[o], src[o + 1]);
+      }
+      if (h == 1) {
+        PH_PIN(v[0].x + v[NH - 1].y);
+        PH_ACC(2, 3);
+      }
+#pragma unroll
+      for (int q = 0; q < NH; q++) {
+        const int it = h * NH + q;
+        if (s0 + 128 * it >= 0 && s0 + 128 * it + 2 <= n) {
+#if FEMASM_EXP == 1
+          asm volatile("" ::"v"(v[q].x), "v"(v[q].y));
+#else
+          store_pair(dstp + 128 * it, v[q]);
+#endif
+        }
+      }
+      asm volatile("" ::: "memory");
+    }
+    if ((head & 1) && lane == 0) runp[0] = sh_stage[0];
+    if (((head + n) & 1) && lane == 1) runp[n - 1] = sh_stage[n - 1];
+    PH_ACC(3, 4);
+    PH_T(0);
+  }
+  if (blockIdx.x == 1 && (blockIdx.y & 15) == 5) {  // profiling build: a sample of the waves, or the flush itself is what is timed
+    PH_FLUSH(8);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // P3 on a verified rectilinear mesh (level 2): one autonomous wave per workgroup, no record wave, no barrier.
 // For dof 1 a tile row of 64 x-consecutive interior nodes is a contiguous 13.8 KB run of the CSR array that ONE
 // wave can own: lane = node, 27 accumulators = its whole row; deposit into a wave-private stage in HBM order (all

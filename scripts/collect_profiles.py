@@ -10,10 +10,10 @@ dst = os.path.join("profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 # tag of make_profiles.sh -> (workload, variant, [kernel name patterns as rocprof prints them], label bench.py uses, nel)
 DOM = {
-    "elastic3d": ("elastic3d", "default", ["k_assemble_rowsweep<2>"], "k_assemble_rowsweep<ELASTIC3D>", 128),
+    "elastic3d": ("elastic3d", "default", ["k_assemble_s3_unit"], "k_assemble_s3_unit", 128),
     "poisson3d": ("poisson3d", "default", ["k_assemble_p3_rect"], "k_assemble_p3_rect", 256),
     "elastic2d": ("elastic2d", "default", ["k_assemble_e2_rect"], "k_assemble_e2_rect", 2048),
-    "elastic3d_manufactured": ("elastic3d", "manufactured", ["k_assemble_rowsweep<2>"], "k_assemble_rowsweep<ELASTIC3D>", 128),
+    "elastic3d_manufactured": ("elastic3d", "manufactured", ["k_assemble_s3_unit"], "k_assemble_s3_unit", 128),
     "elastic3d_general": ("elastic3d", "general", ["k_assemble_sweep<2>"], "k_assemble_sweep<ELASTIC3D>", 128),
     "poisson3d_general": ("poisson3d", "general", ["k_assemble_sweep_p3"], "k_assemble_sweep<POISSON3D>", 256),
     "elastic2d_general": ("elastic2d", "general", ["k_assemble_rows<1>"], "k_assemble_rows<PLANE_STRAIN2D>", 2048),

@@ -489,6 +489,35 @@ def test_s3_rhs_persistent_waves_walk_several_tasks(env, monkeypatch, perturb):
     assert rel(gb.cpu().numpy(), b) <= TOL
 
 
+@pytest.mark.parametrize("variant", ["units=1", "units=3", "units=64", "rowsweep"])
+@pytest.mark.parametrize("dims", [(45, 23, 36), (38, 5, 7), (10, 4, 4)])
+def test_s3_box_kernels_unit_and_rowsweep(env, monkeypatch, variant, dims):
+    """Elastic K on a rectilinear mesh (level 2) has two kernels: k_assemble_s3_unit (default; a wave walks
+    FEMASM_S3_UNITS x-consecutive 8-node units, chosen from the mesh size otherwise, so small meshes only ever see 1)
+    and the persistent k_assemble_rowsweep (FEMASM_S3_ROWSWEEP=1).  Both against the oracle, with a material that
+    differs from element to element, on meshes whose x range is not a multiple of the unit."""
+    torch, F = env["torch"], env["F"]
+    case = make_case(env, "s3", dims, perturb=False)
+    rng = np.random.default_rng(5)
+    props = case["props"].reshape(-1, 400).copy()
+    props[:, 96:104] = rng.uniform(50, 150, size=(props.shape[0], 1))     # one (E, nu) per element
+    props[:, 104:112] = rng.uniform(0.1, 0.4, size=(props.shape[0], 1))
+    case["props"] = props.reshape(-1)
+    M, N, P = dims
+    O = env["O"]
+    K, b = O.assemble_elastic3d(M, N, P, case["coords"], case["props"], case["rp"], case["ci"])
+    O.bc_s3(M, N, P, case["coords"], case["rp"], case["ci"], K, b)
+    if variant == "rowsweep":
+        monkeypatch.setenv("FEMASM_S3_ROWSWEEP", "1")
+    else:
+        monkeypatch.setenv("FEMASM_S3_UNITS", variant.split("=")[1])
+    plan, vals, gb = gpu_assemble(env, case)
+    assert plan.fast_path() == 2
+    assert not np.isnan(vals).any()
+    assert rel(vals, K) <= TOL and rel(gb, b) <= TOL
+    plan.close()
+
+
 @pytest.mark.parametrize("kind", ["e2", "s3"])
 def test_inverted_element_is_reported_by_the_elastic_kinds(env, kind):
     """det J <= 0 at a Gauss point -> FEMASM_ERR_GEOMETRY after the call, on the general kernels the distorted mesh
