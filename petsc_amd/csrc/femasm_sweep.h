@@ -1052,12 +1052,13 @@ __global__ __launch_bounds__(64 * (3 + RowSweep<KIND>::NRW), 2) void k_assemble_
 //   run       deposit in HBM order in the 15.5 KB stage, then 16 B per lane from the 128-byte boundary below the run
 //   prefetch  the next unit's x edge and (E, nu) are requested right after this unit's record is built and before its
 //             stores (loads and stores retire through one in-order counter: a load issued before a store does not
-//             wait for it); the registers it holds (36) are why the kernel runs at two waves per SIMD.
+//             wait for it).
 // Measured (S3 128^3, 254 016 units): one unit per wave 1.09 ms (phase clocks per unit: loads + record
 // 10.4k, rows 5.2k, stage reads 1.3k, stores until acknowledged 4.5k cycles, ten waves per CU), whole line per wave
 // 0.91 ms against 0.93 ms for k_assemble_rowsweep on the same box; without its stores 0.61 ms (row-sweep: 0.89 ms), so
-// neither kernel is at the store roof: this one is bound by its ~800 vector instructions per unit (records rebuilt by the
-// eight lanes that share an element, 216 instructions of cross-lane sums) at eight waves per CU.  Where it clearly wins
+// neither kernel is at the store roof: this one is bound by its ~1 060 instructions per unit (620 vector: records rebuilt
+// by the eight lanes that share an element, 216 for the cross-lane sums; VALU 29 % and LDS 46 % busy, nothing saturated;
+// a third wave per SIMD, a deeper prefetch and conflict-free deposits were each measured and change nothing).  Where it clearly wins
 // is below the headline size: 96^3 0.35 against 0.46 ms, 64^3 0.10 against 0.18 ms, 32^3 0.022 against 0.17 ms (the
 // row-sweep grid has too few workgroups there and a two-layer prologue each).
 // ---------------------------------------------------------------------------
@@ -1072,72 +1073,90 @@ __device__ inline double quad_perm(double v) {
   hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
-// row C of the lane's node from the lane's element; stg = stage + node block + self neighbour
-template <int C>
-__device__ inline void unit_row(const double *pd, const double *pe, const double *po, const double *pq, double *stg,
-                                int pz, int py, int px, int e, bool lower, bool live) {
+#if SU_OCC > 2
+#define SU_SCHED __builtin_amdgcn_sched_barrier(0)  // one piece at a time: interleaved, the pieces' accumulators add up
+#else
+#define SU_SCHED
+#endif
+// row C of the lane's node from the lane's element, the neighbours on the far side (MZ = 1) or on the node's side
+// (MZ = 0) of the element in z; stg = stage + node block + self neighbour
+template <int C, int MZ>
+__device__ inline void unit_half(const double *pd, const double *pe, const double *po, const double *pq, double *stg,
+                                 int pz, int py, int px, int e, bool lower, bool live) {
   constexpr int ia = hex_idx(1, 1, 1);
   constexpr int C1 = (C + 1) % 3, C2 = (C + 2) % 3;
-  double acc[24];  // [mz][my][mx][cc], m = 0: the neighbour on the node's side of the element, 1: the far side
+  double acc[12];  // [my][mx][cc], m = 0: the neighbour on the node's side of the element, 1: the far side
 #pragma unroll
-  for (int mz = 0; mz <= 1; mz++)
+  for (int my = 0; my <= 1; my++)
 #pragma unroll
-    for (int my = 0; my <= 1; my++)
+    for (int mx = 0; mx <= 1; mx++) {
+      const double(*R)[3] = d_refR.R[ia][hex_idx(1 - mx, 1 - my, 1 - MZ)];
+      const int t = my * 2 + mx;
 #pragma unroll
-      for (int mx = 0; mx <= 1; mx++) {
-        const double(*R)[3] = d_refR.R[ia][hex_idx(1 - mx, 1 - my, 1 - mz)];
-        const int t = (mz * 2 + my) * 2 + mx;
-#pragma unroll
-        for (int cc = 0; cc < 3; cc++) {
-          double v = 0.0;
-          if (cc == C) {
-            v = fma(R[C][C], pd[C], v);
-            v = fma(R[C1][C1], pe[C1], v);
-            v = fma(R[C2][C2], pe[C2], v);
-          } else {
-            v = fma(R[C][cc], po[C + cc - 1], v);
-            v = fma(R[cc][C], pq[C + cc - 1], v);
-          }
-          acc[t * 3 + cc] = v;
+      for (int cc = 0; cc < 3; cc++) {
+        double v = 0.0;
+        if (cc == C) {
+          v = fma(R[C][C], pd[C], v);
+          v = fma(R[C1][C1], pe[C1], v);
+          v = fma(R[C2][C2], pe[C2], v);
+        } else {
+          v = fma(R[C][cc], po[C + cc - 1], v);
+          v = fma(R[cc][C], pq[C + cc - 1], v);
         }
+        acc[t * 3 + cc] = v;
       }
-  // the elements that share a neighbour: (oy, ox) partners in the quad, then the other layer
-#pragma unroll
-  for (int mz = 0; mz <= 1; mz++)
-#pragma unroll
-    for (int cc = 0; cc < 3; cc++) {
-      double &a00 = acc[((mz * 2 + 0) * 2 + 0) * 3 + cc], &a01 = acc[((mz * 2 + 0) * 2 + 1) * 3 + cc];
-      double &a10 = acc[((mz * 2 + 1) * 2 + 0) * 3 + cc];
-      a00 += quad_perm<0xB1>(a00);  // ox partner
-      a00 += quad_perm<0x4E>(a00);  // oy partners
-      a01 += quad_perm<0x4E>(a01);  // far in x, same y: the element across y
-      a10 += quad_perm<0xB1>(a10);  // far in y, same x: the element across x
     }
+  // the elements of this layer that share a neighbour: (oy, ox) partners in the quad
+#pragma unroll
+  for (int cc = 0; cc < 3; cc++) {
+    double &a00 = acc[0 * 3 + cc], &a01 = acc[1 * 3 + cc], &a10 = acc[2 * 3 + cc];
+    a00 += quad_perm<0xB1>(a00);  // ox partner
+    a00 += quad_perm<0x4E>(a00);  // oy partners
+    a01 += quad_perm<0x4E>(a01);  // far in x, same y: the element across y
+    a10 += quad_perm<0xB1>(a10);  // far in y, same x: the element across x
+  }
 #if SU_OCC > 2
   // (pinned: the compiler otherwise sinks the last add of every sum into the predicated deposit below and keeps both of
   // its operands alive until then, which doubles the accumulators' registers)
 #pragma unroll
-  for (int q = 0; q < 24; q++) asm volatile("" : "+v"(acc[q]));
+  for (int q = 0; q < 12; q++) asm volatile("" : "+v"(acc[q]));
 #endif
-  // deposit: one exec mask per group of owners (a shared neighbour is written by one of the lanes that hold its sum).
-  // The middle third (mz = 0) is the sum of both element layers: the lanes of layer kn-1 write, then the lanes of
-  // layer kn add theirs in place -- LDS executes a wave's accesses in order, so the second sees the first.
+  // deposit.  A shared neighbour's sum is the same bits in every lane that holds it (the adds above commute), so all of
+  // them write it: no exec mask per group of owners (measured: the 36 predicated blocks per unit cost more issue slots
+  // than the duplicate writes cost LDS cycles).  The middle third (MZ = 0) is the sum of both element layers: the lanes
+  // of layer kn-1 write, then the lanes of layer kn add theirs in place -- LDS executes a wave's accesses in order, so
+  // the second sees the first.
   auto put = [&](double *d, int t, bool add) {
 #pragma unroll
     for (int cc = 0; cc < 3; cc++) d[cc] = add ? d[cc] + acc[t * 3 + cc] : acc[t * 3 + cc];
   };
+  double *d = stg + C * 81 + (MZ ? pz : 0);
+#if FEMASM_EXP == 21  // experiment: every deposit conflict-free (lane-consecutive addresses; wrong values), no stores
+  d = stg + C * 81 + MZ * 36;
+  py = 0, px = 0;
+#endif
+  (void)e;
 #pragma unroll
-  for (int pass = 0; pass < 3; pass++) {  // 0: far third of both layers, 1: middle third from below, 2: from above
-    const int mz = pass == 0 ? 1 : 0;
-    double *d = stg + C * 81 + (mz ? pz : 0);
+  for (int pass = (MZ ? 0 : 1); pass < (MZ ? 1 : 3); pass++) {  // 0: far third, 1: middle third from below, 2: from above
     const bool wz = live && (pass == 0 || (pass == 1) == lower);
     const bool add = pass == 2;
-    if (wz) put(d + py + px, (mz * 2 + 1) * 2 + 1, add);
-    if (wz && (e & 1) == 0) put(d + py, (mz * 2 + 1) * 2 + 0, add);
-    if (wz && (e & 2) == 0) put(d + px, (mz * 2 + 0) * 2 + 1, add);
-    if (wz && e == 0) put(d, (mz * 2 + 0) * 2 + 0, add);
+    if (wz) {
+      put(d + py + px, 3, add);
+      put(d + py, 2, add);
+      put(d + px, 1, add);
+      put(d, 0, add);
+    }
     if (pass == 1) asm volatile("" ::: "memory");
   }
+}
+template <int C>
+__device__ inline void unit_row(const double *pd, const double *pe, const double *po, const double *pq, double *stg,
+                                int pz, int py, int px, int e, bool lower, bool live) {
+  SU_SCHED;
+  unit_half<C, 1>(pd, pe, po, pq, stg, pz, py, px, e, lower, live);
+  SU_SCHED;
+  unit_half<C, 0>(pd, pe, po, pq, stg, pz, py, px, e, lower, live);
+  SU_SCHED;
 }
 __global__ __launch_bounds__(64, SU_OCC) void k_assemble_s3_unit(const Slab s, const KArgs a) {
   using R_ = RowSweep<KIND_ELASTIC>;
@@ -1159,21 +1178,23 @@ __global__ __launch_bounds__(64, SU_OCC) void k_assemble_s3_unit(const Slab s, c
     const int64_t kc = k < s.cks ? s.cks : (k > a.cke - 1 ? a.cke - 1 : k);
     return a.coords[3 * (M * N * (kc - s.cks)) + 2];
   };
-  // what a unit reads: the x edge of the lane's element and its (E, nu) at the eight Gauss points; issued one unit
+  // what a unit reads: the x edge of the lane's element and its (E, nu) at the eight Gauss points; requested one unit
   // ahead, right after the previous unit's record is built (the registers are free again) and before its stores:
-  // gfx9 retires loads and stores in one in-order counter, so a load issued BEFORE a store does not wait for it
-  double xa, xb, m[16];
-  auto load_unit = [&](int64_t i0) {
+  // gfx9 retires loads and stores in one in-order counter, so a load issued BEFORE a store does not wait for it.
+  // (Two units ahead, with a second register set: measured the same 0.905 ms, so the load latency is covered.)
+  struct UnitIn { double xa, xb, m[16]; };
+  UnitIn inA;
+  auto load_unit = [&](int64_t i0, UnitIn &in) {
     const int nv = (a.x1 - i0 < SU_TX) ? (int)(a.x1 - i0) : SU_TX;
     const int64_t gex = i0 + (lx < nv ? lx : nv - 1) + ox;
-    xa = a.coords[3 * gex], xb = a.coords[3 * (gex + 1)];
+    in.xa = a.coords[3 * gex], in.xb = a.coords[3 * (gex + 1)];
     if (aos) {
       const double *mq = a.gp + (gex + (M - 1) * (gey + (N - 1) * (L - s.mat_e_ks))) * a.mat_stride + 96;
 #pragma unroll
-      for (int q = 0; q < 16; q++) m[q] = mq[q];
+      for (int q = 0; q < 16; q++) in.m[q] = mq[q];
     }
   };
-  if (ifirst < a.x1) load_unit(ifirst);
+  if (ifirst < a.x1) load_unit(ifirst, inA);
   // the y and z edges are those of the whole line (k_check_rectilinear has verified that the three coordinate lines
   // describe the mesh)
   const double ya = a.coords[3 * (M * gey) + 1], yb = a.coords[3 * (M * (gey + 1)) + 1];
@@ -1185,11 +1206,17 @@ __global__ __launch_bounds__(64, SU_OCC) void k_assemble_s3_unit(const Slab s, c
   const double s01 = sx * sy, s02 = sx * sz, s12 = sy * sz;
   // far-side neighbour steps in the node block: (dz, dy, dx) -> ((dz+1)*9 + (dy+1)*3 + (dx+1)) * 3 + column dof
   const int pz = AS ? -27 : 27, py = oy ? -9 : 9, px = ox ? -3 : 3;
+#if FEMASM_EXP == 21
+  double *stg = sh_stage + lane;
+#else
   double *stg = sh_stage + lx * NB + 39;
+#endif
   const bool lower = AS == 1;
-  for (int u = 0; u < NU; u++) {
+  auto unit = [&](int u, UnitIn &in) -> bool {
     const int64_t i0 = ifirst + (int64_t)u * SU_TX;
-    if (i0 >= a.x1) break;
+    if (i0 >= a.x1) return false;
+    const double xa = in.xa, xb = in.xb;
+    const double(&m)[16] = in.m;
     const int nvx = (a.x1 - i0 < SU_TX) ? (int)(a.x1 - i0) : SU_TX;
     const bool live = lx < nvx;
     double pd[3], pe[3], po[3], pq[3];
@@ -1222,7 +1249,7 @@ __global__ __launch_bounds__(64, SU_OCC) void k_assemble_s3_unit(const Slab s, c
     }
     PH_PIN(pd[0] + pq[2]);
     PH_ACC(0, 1);
-    if (u + 1 < NU && i0 + SU_TX < a.x1) load_unit(i0 + SU_TX);
+    if (u + 1 < NU && i0 + SU_TX < a.x1) load_unit(i0 + SU_TX, in);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();  // the previous unit's reads of the stage are done
     unit_row<0>(pd, pe, po, pq, stg, pz, py, px, e, lower, live);
@@ -1242,40 +1269,51 @@ __global__ __launch_bounds__(64, SU_OCC) void k_assemble_s3_unit(const Slab s, c
     const int s0 = 2 * lane - head;
     const double *src = sh_stage + s0;
     double *dstp = runp + s0;
-    constexpr int NH = NIT / 2;  // two halves: 16 chunks in flight would cost 64 registers next to the prefetched unit
-    static_assert(NIT % 2 == 0, "store rounds");
+    constexpr int NPART = SU_OCC > 2 ? 4 : 2, NH = NIT / NPART;  // in parts: 16 chunks in flight would cost 64 registers
+    static_assert(NIT % NPART == 0, "store rounds");
+    // full = a whole unit (wave-uniform): only the first round can start below the run and only the last rounds can end
+    // beyond it; the rounds between need no exec mask (an exec mask per round costs four scalar issue slots)
+    auto copy_out = [&](auto full_tag) {
+      constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-      double2 v[NH];
+      for (int h = 0; h < NPART; h++) {
+        double2 v[NH];
 #pragma unroll
-      for (int q = 0; q < NH; q++) {
-        const int it = h * NH + q;
-        int o = 128 * it;
-        if (128 * (it + 1) > RUN + PAD) o = (s0 + o + 2 <= RUN + PAD) ? o : 0;  // last round: stay inside the array
-        v[q] = make_double2(src[o], src[o + 1]);
-      }
-      if (h == 1) {
-        PH_PIN(v[0].x + v[NH - 1].y);
-        PH_ACC(2, 3);
-      }
-#pragma unroll
-      for (int q = 0; q < NH; q++) {
-        const int it = h * NH + q;
-        if (s0 + 128 * it >= 0 && s0 + 128 * it + 2 <= n) {
-#if FEMASM_EXP == 1
-          asm volatile("" ::"v"(v[q].x), "v"(v[q].y));
-#else
-          store_pair(dstp + 128 * it, v[q]);
-#endif
+        for (int q = 0; q < NH; q++) {
+          const int it = h * NH + q;
+          int o = 128 * it;
+          if (128 * (it + 1) > RUN + PAD) o = (s0 + o + 2 <= RUN + PAD) ? o : 0;  // last round: stay inside the array
+          v[q] = make_double2(src[o], src[o + 1]);
         }
+        if (h == NPART - 1) {
+          PH_PIN(v[0].x + v[NH - 1].y);
+          PH_ACC(2, 3);
+        }
+#pragma unroll
+        for (int q = 0; q < NH; q++) {
+          const int it = h * NH + q;
+          const bool always = FULL && it > 0 && 2 * 63 + 128 * it + 2 <= RUN;
+          if (always || (s0 + 128 * it >= 0 && s0 + 128 * it + 2 <= n)) {
+#if FEMASM_EXP == 1 || FEMASM_EXP == 21
+            asm volatile("" ::"v"(v[q].x), "v"(v[q].y));
+#else
+            store_pair(dstp + 128 * it, v[q]);
+#endif
+          }
+        }
+        asm volatile("" ::: "memory");
       }
-      asm volatile("" ::: "memory");
-    }
+    };
+    if (nvx == SU_TX) copy_out(std::true_type{});
+    else copy_out(std::false_type{});
     if ((head & 1) && lane == 0) runp[0] = sh_stage[0];
     if (((head + n) & 1) && lane == 1) runp[n - 1] = sh_stage[n - 1];
     PH_ACC(3, 4);
     PH_T(0);
-  }
+    return true;
+  };
+  for (int u = 0; u < NU; u++)
+    if (!unit(u, inA)) break;
   if (blockIdx.x == 1 && (blockIdx.y & 15) == 5) {  // profiling build: a sample of the waves, or the flush itself is what is timed
     PH_FLUSH(8);
   }
