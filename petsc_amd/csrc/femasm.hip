@@ -295,7 +295,9 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
         p->e2_b0 = y0;
         p->e2_b1 = y1;
       }
-      dim3 grid((unsigned)((b.x1 - b.x0 + RS2_TX - 1) / RS2_TX), (unsigned)((y1 - y0 + E2W_YC - 1) / E2W_YC), 1);
+      const char *yc_env = getenv("FEMASM_E2_YC");  // node rows per wave
+      a.zc = yc_env ? std::max(1, atoi(yc_env)) : E2W_YC;
+      dim3 grid((unsigned)((b.x1 - b.x0 + RS2_TX - 1) / RS2_TX), (unsigned)((y1 - y0 + a.zc - 1) / a.zc), 1);
       if (timed) HIPCHK(hipEventRecord(p->ev[4], p->stream));
       if (a.bout) hipLaunchKernelGGL(k_assemble_e2_rect<true>, grid, dim3(64), 0, p->stream, p->s, a);
       else hipLaunchKernelGGL(k_assemble_e2_rect<false>, grid, dim3(64), 0, p->stream, p->s, a);

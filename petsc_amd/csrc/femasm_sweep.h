@@ -1272,7 +1272,9 @@ __global__ __launch_bounds__(64, SU_OCC) void k_assemble_s3_unit(const Slab s, c
     constexpr int NPART = SU_OCC > 2 ? 4 : 2, NH = NIT / NPART;  // in parts: 16 chunks in flight would cost 64 registers
     static_assert(NIT % NPART == 0, "store rounds");
     // full = a whole unit (wave-uniform): only the first round can start below the run and only the last rounds can end
-    // beyond it; the rounds between need no exec mask (an exec mask per round costs four scalar issue slots)
+    // beyond it; the rounds between need no exec mask (an exec mask per round costs four scalar issue slots; measured
+    // 0.898 against 0.913 ms with every round predicated.  The same change in k_assemble_p3_rect / k_assemble_e2_rect
+    // measured SLOWER there, 0.74 against 0.68 ms and 0.423 against 0.414 ms, and was not kept)
     auto copy_out = [&](auto full_tag) {
       constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
@@ -1508,8 +1510,8 @@ __global__ __launch_bounds__(64) void k_assemble_e2_rect(const Slab s, const KAr
   const int lane = threadIdx.x;
   const int64_t M = s.dim[0];
   const int64_t i0 = a.x0 + (int64_t)blockIdx.x * RS2_TX;
-  const int64_t yc0 = a.s0 + (int64_t)blockIdx.y * E2W_YC;
-  const int64_t yc1 = (yc0 + E2W_YC < a.s1) ? yc0 + E2W_YC : a.s1;
+  const int64_t yc0 = a.s0 + (int64_t)blockIdx.y * a.zc;  // a.zc node rows per wave (E2W_YC; 2 ... 64 measure the same)
+  const int64_t yc1 = (yc0 + a.zc < a.s1) ? yc0 + a.zc : a.s1;
   const int ny = (int)(yc1 - yc0);
   const int nvx = (a.x1 - i0 < RS2_TX) ? (int)(a.x1 - i0) : RS2_TX;
   const int64_t i = (lane < nvx) ? i0 + lane : i0 + nvx - 1;  // idle lanes repeat the last node
