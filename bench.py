@@ -373,6 +373,8 @@ def main():
                 kernel = "k_assemble_p3_rect"
             if wl == "elastic3d" and level == 2 and not os.environ.get("FEMASM_S3_ROWSWEEP"):
                 kernel = "k_assemble_s3_unit"
+            if wl == "poisson3d" and level == 0 and not os.environ.get("FEMASM_P3_SWEEP"):
+                kernel = "k_assemble_ke_p3"
         traffic = measured_traffic(wl, nel, world, args)
         out = {
             "metric": "global assembly elements/sec + achieved HBM GB/s fraction",

@@ -400,7 +400,12 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
       } else {
         dim3 grid((unsigned)((b.x1 - b.x0 + SW_TX - 1) / SW_TX), (unsigned)((b.y1 - b.y0 + SW_TY - 1) / SW_TY),
                   (unsigned)((z1 - z0 + SW_ZC - 1) / SW_ZC));
-        if (KIND == KIND_POISSON) hipLaunchKernelGGL(k_assemble_sweep_p3, grid, dim3(256), 0, p->stream, p->s, a);
+        if (KIND == KIND_POISSON && !getenv("FEMASM_P3_SWEEP")) {
+          // element matrices through LDS (FEMASM_P3_SWEEP=1: the node-row kernel of round 1, for A/B)
+          dim3 gke((unsigned)((b.x1 - b.x0 + KE_TX - 1) / KE_TX), (unsigned)((b.y1 - b.y0 + KE_TY - 1) / KE_TY),
+                   (unsigned)((z1 - z0 + KE_ZC - 1) / KE_ZC));
+          hipLaunchKernelGGL(k_assemble_ke_p3, gke, dim3(256), 0, p->stream, p->s, a);
+        } else if (KIND == KIND_POISSON) hipLaunchKernelGGL(k_assemble_sweep_p3, grid, dim3(256), 0, p->stream, p->s, a);
         else hipLaunchKernelGGL(k_assemble_sweep<KIND>, grid, dim3(256), 0, p->stream, p->s, a);
       }
       HIPCHK(hipGetLastError());

@@ -452,6 +452,216 @@ __global__ __launch_bounds__(256, 2) void k_assemble_sweep_p3(const Slab s, cons
 }
 
 // ---------------------------------------------------------------------------
+// General path for P3, element matrices through LDS: k_assemble_ke_p3.
+// k_assemble_sweep_p3 is bound by FP64 issue: every node row forms its 27 entries from the Gauss-point records itself,
+// 8 elements x 8 nodes x 8 Gauss points x 6 FMAs = 3072 FMAs per node, and each entry K_ab of an element is formed
+// twice (in the row of a and in the row of b).  Here the element matrix is formed ONCE, its 36 unique entries
+// (a <= b) only, and the node rows pick their entries out of LDS:
+//   tile      15 x 3 interior nodes, i.e. 16 x 4 = 64 elements per element layer: lane = element in the two element
+//             phases, lane = node (45 of 64 busy) in the cheap gather
+//   records   wave w: C_p = detJ iJ^T iJ of Gauss points 2w, 2w+1 of element `lane` (the arithmetic of
+//             k_assemble_sweep_p3), pair-SoA in LDS, slot = lane: conflict-free 16-byte reads
+//   Ke        wave w: entries 9w .. 9w+8 of the 36, each sum_p ghat_a^T C_p ghat_b with literal coefficients
+//             (48 FMAs), written to sh_ke[element * 37 + entry] (37: conflict-free for the gather's stride)
+//   gather    the wave roles of k_assemble_sweep (lower third of layer L+1, start / finish of the middle third, upper
+//             third of layer L): 16 LDS reads and adds per node and role, in a fixed order
+//   stores    per-wave LDS transposition as in k_assemble_sweep (216-byte runs)
+// Per element layer a wave issues 2 x ~140 + 432 FMAs for 45 nodes where k_assemble_sweep_p3 issues 4 x ~140 + 1536
+// for 64.  Sums are formed element by element and then over the elements -- the reference's own order (Ke, then
+// ADD_VALUES), rounding differs from k_assemble_sweep_p3 in the last bit.
+// ---------------------------------------------------------------------------
+constexpr int KE_TX = 15, KE_TY = 3, KE_ZC = 16, KE_KS = 37;
+struct KePairs { int a[36], b[36], idx[8][8]; };
+constexpr KePairs make_ke_pairs() {
+  KePairs o{};
+  int n = 0;
+  for (int a = 0; a < 8; a++)
+    for (int b = a; b < 8; b++) {
+      o.a[n] = a;
+      o.b[n] = b;
+      o.idx[a][b] = o.idx[b][a] = n;
+      n++;
+    }
+  return o;
+}
+__device__ const KePairs KE_PAIRS = make_ke_pairs();  // const + constant initialiser: folded after unrolling
+
+template <int W>
+__device__ inline void ke_entries_p3(const double2 *__restrict__ rec /* sh_rec + lane */, double *__restrict__ ke) {
+  double v[9];
+#pragma unroll
+  for (int q = 0; q < 9; q++) v[q] = 0.0;
+#pragma unroll
+  for (int p = 0; p < 8; p++) {
+    const double2 c0 = rec[(3 * p) * 64], c1 = rec[(3 * p + 1) * 64], c2 = rec[(3 * p + 2) * 64];
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+      const double *k = d_refGP.c[p][KE_PAIRS.a[9 * W + q]][KE_PAIRS.b[9 * W + q]];
+      double t = v[q];
+      t = fma(k[0], c0.x, t);
+      t = fma(k[1], c0.y, t);
+      t = fma(k[2], c1.x, t);
+      t = fma(k[3], c1.y, t);
+      t = fma(k[4], c2.x, t);
+      t = fma(k[5], c2.y, t);
+      v[q] = t;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 9; q++) ke[9 * W + q] = v[q];
+}
+// the entries of the four elements of one element layer that belong to the node's row: AS = 1: the node is on the
+// top face of these elements; OBS: the neighbours on their bottom (0) or top (1) face
+template <int AS, int OBS>
+__device__ inline void ke_gather_p3(const double *__restrict__ ke, int lx, int ly, double *acc) {
+#pragma unroll
+  for (int oy = -1; oy <= 0; oy++)
+#pragma unroll
+    for (int ox = -1; ox <= 0; ox++) {
+      const double *kp = ke + ((lx + 1 + ox) + 16 * (ly + 1 + oy)) * KE_KS;
+      const int ia = hex_idx(-ox, -oy, AS);
+#pragma unroll
+      for (int by = 0; by <= 1; by++)
+#pragma unroll
+        for (int bx = 0; bx <= 1; bx++) {
+          const int t = (oy + by + 1) * 3 + (ox + bx + 1);
+          acc[t] = acc[t] + kp[KE_PAIRS.idx[ia][hex_idx(bx, by, OBS)]];
+        }
+    }
+}
+// one third (dz) of the rows of the wave's nodes (lane = lx + 16 ly, lx < nvx, ly < nvy) -> per-wave LDS area ->
+// 72-byte pieces of the rows, consecutive lanes on consecutive values
+__device__ inline void ke_store_third(const Slab &s, const KArgs &a, const double *acc, double *stage, int lane, int64_t i0,
+                                      int64_t j0, int64_t kn, int dz, int nvx, int nvy) {
+  constexpr int CH = 9, NODESTRIDE = 27;
+  constexpr int NIT = (16 * CH + 63) / 64;
+  int goff[NIT];  // position of staged value idx in the node-major CSR run of a tile row
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    const int idx = lane + 64 * it;
+    goff[it] = idx + (NODESTRIDE - CH) * (idx / CH);
+  }
+#pragma unroll
+  for (int t = 0; t < 9; t++) stage[lane * CH + t] = acc[t];
+  __builtin_amdgcn_wave_barrier();
+  for (int rr = 0; rr < nvy; rr++) {
+    double *base = a.out + (row_start(s, i0, j0 + rr, kn, 0) - a.base_off) + (dz + 1) * CH;
+    const double *src = stage + rr * (16 * CH);
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int idx = lane + 64 * it;
+#if FEMASM_EXP == 1
+      if (idx < nvx * CH) asm volatile("" ::"v"(src[idx]), "v"(base));
+#else
+      if (idx < nvx * CH) base[goff[it]] = src[idx];
+#endif
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(256, 3) void k_assemble_ke_p3(const Slab s, const KArgs a) {
+  if (a.cond && a.bad[1] == 0) return;
+  constexpr int NACC = 9, NPAIR = 24, CH = 9, XS = 17, YS = 5;
+  __shared__ double2 sh_rec[NPAIR * 64];          // C_p of the 8 Gauss points, pair-SoA rec[3p + q][element]
+  __shared__ double sh_ke[64 * KE_KS];             // the 36 unique entries of the 64 element matrices
+  __shared__ double sh_x[2 * XS * YS * 3];         // node layers L, L+1 of the halo'd tile
+  static_assert(3 * 64 * CH * 8 <= NPAIR * 64 * 16, "staging aliases the record buffer");
+  double *sh_stage = reinterpret_cast<double *>(sh_rec);  // per storing wave; the records are dead once Ke is formed
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lx = lane & 15, ly = lane >> 4;        // node of the tile (lx < 15, ly < 3) / element of the layer
+  const int64_t M = s.dim[0], N = s.dim[1];
+  const int64_t i0 = a.x0 + (int64_t)blockIdx.x * KE_TX, j0 = a.y0 + (int64_t)blockIdx.y * KE_TY;
+  const int64_t zc0 = a.s0 + (int64_t)blockIdx.z * KE_ZC;
+  const int64_t zc1 = (zc0 + KE_ZC < a.s1) ? zc0 + KE_ZC : a.s1;
+  const int nsteps = (int)(zc1 - zc0) + 1;
+  const int nvx = (a.x1 - i0 < KE_TX) ? (int)(a.x1 - i0) : KE_TX;
+  const int nvy = (a.y1 - j0 < KE_TY) ? (int)(a.y1 - j0) : KE_TY;
+  const bool mynode = lx < KE_TX && ly < KE_TY;
+  const int glx = mynode ? lx : 0, gly = mynode ? ly : 0;  // idle lanes gather node (0, 0) again: no LDS read out of range
+  double *stage = sh_stage + ((w == 0) ? 0 : (w == 3 ? 1 : 2)) * (64 * CH);
+  double acc[NACC];
+#pragma unroll
+  for (int q = 0; q < NACC; q++) acc[q] = 0.0;
+
+  for (int st = 0; st < nsteps; st++) {
+    const int64_t L = zc0 - 1 + st;  // element layer of this step
+    // node coordinates of layers L, L+1 (clamped reads).  (Requesting the new layer a step ahead through registers was
+    // measured 3 % slower: the other workgroups of the CU cover the wait, the extra registers and code do not pay.)
+    for (int q = tid; q < 2 * XS * YS; q += 256) {
+      const int cz = q / (XS * YS), rem = q - (XS * YS) * cz, cy = rem / XS, cx = rem - XS * cy;
+      int64_t gi = i0 - 1 + cx, gj = j0 - 1 + cy, gk = L + cz;
+      gi = gi < 0 ? 0 : (gi > M - 1 ? M - 1 : gi);
+      gj = gj < 0 ? 0 : (gj > N - 1 ? N - 1 : gj);
+      gk = gk < s.cks ? s.cks : (gk > a.cke - 1 ? a.cke - 1 : gk);
+      const int64_t node = gi + M * (gj + N * (gk - s.cks));
+#pragma unroll
+      for (int d = 0; d < 3; d++) sh_x[3 * q + d] = a.coords[3 * node + d];
+    }
+    __syncthreads();  // coordinates staged; every wave is through the previous step's gather and stores
+
+    {  // records: wave w builds Gauss points 2w and 2w+1 of element `lane` = (ex, ey) = (lx, ly)
+      const int64_t gex = i0 - 1 + lx, gey = j0 - 1 + ly;
+      const bool eok = gex >= 0 && gex < M - 1 && gey >= 0 && gey < N - 1 && L >= s.els && L < s.ele;
+#pragma unroll 1
+      for (int pp = 0; pp < 2; pp++) {
+        const int p = 2 * w + pp;
+        const double(*G)[8] = c_tab3.G[p];
+        double2 *dst = sh_rec + (3 * p) * 64 + lane;
+        double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+        for (int n = 0; n < 8; n++) {
+          const double *xn = sh_x + 3 * ((lx + HDI[n]) + XS * ((ly + HDJ[n]) + YS * HDK[n]));
+          const double x0 = xn[0], x1 = xn[1], x2 = xn[2];
+#pragma unroll
+          for (int rr = 0; rr < 3; rr++) {
+            J[rr][0] = J[rr][0] + G[rr][n] * x0;
+            J[rr][1] = J[rr][1] + G[rr][n] * x1;
+            J[rr][2] = J[rr][2] + G[rr][n] * x2;
+          }
+        }
+        double iJ[3][3], det;
+        inv3_ref(J, iJ, det);
+        const double wJ = 1.0 * det;
+        if (eok && !(wJ > 0.0)) atomicAdd(a.bad, 1ULL);
+        double Cm[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+          for (int l = k; l < 3; l++) Cm[k][l] = (iJ[0][k] * iJ[0][l] + iJ[1][k] * iJ[1][l] + iJ[2][k] * iJ[2][l]) * wJ;
+        dst[0] = eok ? make_double2(Cm[0][0], Cm[1][1]) : make_double2(0.0, 0.0);
+        dst[64] = eok ? make_double2(Cm[2][2], Cm[0][1]) : make_double2(0.0, 0.0);
+        dst[2 * 64] = eok ? make_double2(Cm[0][2], Cm[1][2]) : make_double2(0.0, 0.0);
+      }
+    }
+    __syncthreads();  // records complete
+    if (w == 0)      ke_entries_p3<0>(sh_rec + lane, sh_ke + lane * KE_KS);
+    else if (w == 1) ke_entries_p3<1>(sh_rec + lane, sh_ke + lane * KE_KS);
+    else if (w == 2) ke_entries_p3<2>(sh_rec + lane, sh_ke + lane * KE_KS);
+    else             ke_entries_p3<3>(sh_rec + lane, sh_ke + lane * KE_KS);
+    __syncthreads();  // element matrices complete
+
+    int role;
+    if (w == 0) role = 0;
+    else if (w == 3) role = 3;
+    else role = ((st + w) & 1) ? 1 : 2;
+    const int64_t kn = (role < 2) ? L + 1 : L;
+    const bool active = (role < 2) ? (kn < zc1) : (kn >= zc0);
+    if (role != 2) {
+#pragma unroll
+      for (int q = 0; q < NACC; q++) acc[q] = 0.0;
+    }
+    if (active) {
+      if (role == 0)      ke_gather_p3<1, 0>(sh_ke, glx, gly, acc);
+      else if (role == 1) ke_gather_p3<1, 1>(sh_ke, glx, gly, acc);
+      else if (role == 2) ke_gather_p3<0, 0>(sh_ke, glx, gly, acc);
+      else                ke_gather_p3<0, 1>(sh_ke, glx, gly, acc);
+      if (role != 1) ke_store_third(s, a, acc, stage, lane, i0, j0, kn, (role == 0) ? -1 : (role == 2 ? 0 : 1), nvx, nvy);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Affine fast path.  When an element is a parallelepiped (its twelve edges are three exactly equal
 // quadruples -- true for every element of DMDASetUniformCoordinates meshes, P3:663, S3:1198) the Jacobian
 // is the same at all Gauss points, so with Gauss-point-constant material

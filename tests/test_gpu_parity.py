@@ -518,6 +518,22 @@ def test_s3_box_kernels_unit_and_rowsweep(env, monkeypatch, variant, dims):
     plan.close()
 
 
+@pytest.mark.parametrize("kernel", ["ke", "sweep"])
+@pytest.mark.parametrize("dims", [(33, 9, 21), (17, 5, 4), (4, 3, 5), (47, 12, 35)])
+def test_p3_general_kernels_element_matrix_and_node_row(env, monkeypatch, kernel, dims):
+    """Poisson K on general hexahedra has two kernels: k_assemble_ke_p3 (default: the 36 unique entries of each element
+    matrix formed once, node rows gathered from LDS; 15 x 3 node tiles) and the node-row kernel k_assemble_sweep_p3
+    (FEMASM_P3_SWEEP=1).  Both against the oracle on perturbed meshes whose extents are not multiples of either tile."""
+    case = make_case(env, "p3", dims, perturb=True)
+    if kernel == "sweep":
+        monkeypatch.setenv("FEMASM_P3_SWEEP", "1")
+    plan, vals, gb = gpu_assemble(env, case)
+    assert plan.fast_path() == 0
+    assert not np.isnan(vals).any()
+    assert rel(vals, case["K"]) <= TOL and rel(gb, case["b"]) <= TOL
+    plan.close()
+
+
 @pytest.mark.parametrize("kind", ["e2", "s3"])
 def test_inverted_element_is_reported_by_the_elastic_kinds(env, kind):
     """det J <= 0 at a Gauss point -> FEMASM_ERR_GEOMETRY after the call, on the general kernels the distorted mesh
