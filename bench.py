@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--nel", type=int, default=0, help="elements per direction (default: 128 / 256 / 2048)")
     ap.add_argument("--perturb", action="store_true", help="general (non-affine) geometry variant")
     ap.add_argument("--uniform-material", action="store_true", help="uniform E,nu instead of the AoS array")
+    ap.add_argument("--element-soa", action="store_true",
+                    help="elastic kinds, one GPU: FEMASM_MAT_ELEMENT_SOA (E and nu per element, two planes) instead of the\n"
+                         "drivers' AoS records; carries no loads, so use with --k-only")
     ap.add_argument("--manufactured-loads", action="store_true",
                     help="elastic3d: FEMASM_MAT_MANUFACTURED (f and grad u evaluated in the RHS kernel, constant E, nu) "
                          "instead of streaming the drivers' AoS records")
@@ -160,7 +163,7 @@ def measured_traffic(wl, nel, world, args):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*/traffic.json,
     FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs of this same command and corrected
     as MI355X_MICROARCH.md prescribes).  None when this exact configuration was not profiled."""
-    if world != 1 or args.uniform_material or args.k_only or args.fast_level != 2:
+    if world != 1 or args.uniform_material or args.k_only or args.fast_level != 2 or args.element_soa:
         return None
     if wl == "enriched3d" and args.n_enr != 1:
         return None
@@ -252,6 +255,11 @@ def main():
         # the drivers' GaussPointCoefficients fill (S3:1243-1363 / E2:618-670), on device (row N1)
         material = torch.empty(plan.nel * stride, dtype=torch.float64, device=dev)
         plan.fill_properties(material, E, nu, stride)
+        if args.element_soa:
+            assert world == 1, "--element-soa: one GPU"
+            material = torch.cat([torch.full((plan.nel,), E, dtype=torch.float64, device=dev),
+                                  torch.full((plan.nel,), nu, dtype=torch.float64, device=dev)])
+            stride = plan.nel
     vals = torch.empty(plan.nnz, dtype=torch.float64, device=dev)
     b = None if args.k_only else torch.empty(plan.nrows, dtype=torch.float64, device=dev)
 
@@ -285,7 +293,8 @@ def main():
             reqs = slab.exchange_interface_start(send if rank > 0 else None, recv if rank < world - 1 else None,
                                                  rank, world)
         st = plan.assemble_system(vals, b, material=material, stride=stride, bc=bc, E=E, nu=nu, e_ks=els,
-                                  want_stats=True, manufactured=args.manufactured_loads and wl == "elastic3d")
+                                  want_stats=True, manufactured=args.manufactured_loads and wl == "elastic3d",
+                                  element_soa=args.element_soa and material is not None)
         if world > 1:
             slab.exchange_interface_finish(reqs)
             plan.interface_apply(vals, b, bc=bc)
@@ -400,7 +409,9 @@ def main():
                 "rows_per_gpu": int(st.nrows),
                 "nnz_per_gpu": int(st.nnz),
                 "material": ("manufactured loads evaluated in-kernel, constant E, nu" if args.manufactured_loads else
-                             "uniform") if material is None else f"AoS GaussPointCoefficients stride {stride}",
+                             "uniform") if material is None else
+                            ("per-element (E, nu) planes (FEMASM_MAT_ELEMENT_SOA)" if args.element_soa else
+                             f"AoS GaussPointCoefficients stride {stride}"),
                 "parallelism": f"z-slab x{world}, interface rows exchanged over RCCL p2p" if world > 1 else "1 GPU",
             },
             "roofline": {

@@ -64,11 +64,19 @@ enum {
    * kernel at the Gauss-point positions it derives from the coordinates -- the fill loop S3:1243-1363 and the
    * 2 304 bytes per element that AssembleF_Elasticity (S3:720-803) reads back from it are not needed.  Same b as from
    * the records the drivers fill, to rounding.  FEMASM_MAT_AOS stays the drop-in default. */
-  FEMASM_MAT_MANUFACTURED = 2
+  FEMASM_MAT_MANUFACTURED = 2,
+  /* Compact per-element form (A14: "should also accept a compact SoA/uniform form"; no counterpart in the reference,
+   * whose records repeat one (E, nu) at every Gauss point wherever the material is element-wise constant): two planes of
+   * doubles in device memory, E of element e at gp[e], nu at gp[stride + e], e = ei + mx*(ej + my*(ek - e_ks));
+   * stride = distance between the planes in doubles (>= the elements held).  16 B per element instead of the 128-B
+   * line of a 3 200-B record.  It carries no loads: K (and femasm_apply_operator) use it; a right-hand side asked for
+   * in the same call holds the Dirichlet data only, as with FEMASM_MAT_UNIFORM.  Not for the enriched kind.
+   * The same (E, nu) through FEMASM_MAT_AOS records gives the same K bit for bit (tested). */
+  FEMASM_MAT_ELEMENT_SOA = 3
 };
 typedef struct {
-  int32_t layout;       /* FEMASM_MAT_AOS | FEMASM_MAT_UNIFORM (K only needs E,nu)            */
-  int32_t stride;       /* doubles per element: 24 (E2) | 400 (S3) | 408/416 (R3)             */
+  int32_t layout;       /* FEMASM_MAT_AOS | _UNIFORM | _MANUFACTURED | _ELEMENT_SOA (K only needs E,nu) */
+  int32_t stride;       /* doubles per element: 24 (E2) | 400 (S3) | 408/416 (R3); _ELEMENT_SOA: plane distance */
   int64_t e_ks;         /* first element layer held in gp[] (owned elements start here)       */
   const double *gp;     /* element index ei + mx*(ej + my*(ek - e_ks))                        */
   double E, nu;         /* FEMASM_MAT_UNIFORM                                                 */

@@ -233,13 +233,23 @@ int64_t layer_nnz(const Slab &s, int64_t l0, int64_t l1) {
 
 struct Box { int64_t x0, x1, y0, y1, s0, s1; };
 
+// FEMASM_MAT_ELEMENT_SOA: two device planes that cover the slab's elements from e_ks on
+static const char *check_element_soa(const femasm_plan *p, const femasm_material &m) {
+  const Slab &s = p->s;
+  const int64_t eplane = (s.nsd == 3) ? (s.dim[0] - 1) * (s.dim[1] - 1) : (s.dim[0] - 1);
+  if (!m.gp || !is_device_ptr(m.gp)) return "the per-element (E, nu) planes must be in device memory";
+  if (m.e_ks > s.els) return "material starts above the first assembled element layer";
+  if ((int64_t)m.stride < eplane * (s.ele - m.e_ks)) return "material stride (plane distance) is smaller than the elements held";
+  return nullptr;
+}
+
 template <int KIND>
 KArgs make_kargs(femasm_plan *p, const femasm_material *mat, int bc, double *out, const Box &b, int64_t base_s0,
                  int iface) {
   using T = Traits<KIND>;
   KArgs a{};
   a.coords = p->coords;
-  a.gp = (mat && mat->layout == FEMASM_MAT_AOS) ? p->gp_cur : nullptr;
+  a.gp = (mat && (mat->layout == FEMASM_MAT_AOS || mat->layout == FEMASM_MAT_ELEMENT_SOA)) ? p->gp_cur : nullptr;
   a.out = out;
   a.bad = p->bad;
   a.base_off = (T::NSD == 3) ? row_start(p->s, 0, 0, base_s0, 0) : row_start(p->s, 0, base_s0, 0, 0);
@@ -1053,10 +1063,12 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
       if (mloc.stride < need) return fail(FEMASM_ERR_ARG, "material stride %d < %d", mloc.stride, need);
       if (mloc.e_ks > s.els) return fail(FEMASM_ERR_ARG, "material starts at element layer %lld > %lld",
                                          (long long)mloc.e_ks, (long long)s.els);
+    } else if (mloc.layout == FEMASM_MAT_ELEMENT_SOA) {
+      if (const char *why = check_element_soa(p, mloc)) return fail(FEMASM_ERR_ARG, "%s", why);
     } else if (mloc.layout != FEMASM_MAT_UNIFORM && !(mloc.layout == FEMASM_MAT_MANUFACTURED && p->kind == KIND_ELASTIC)) {
       return fail(FEMASM_ERR_ARG, "unknown material layout %d", mloc.layout);
     }
-    p->s.mat_e_ks = (mloc.layout == FEMASM_MAT_AOS) ? mloc.e_ks : s.els;
+    p->s.mat_e_ks = (mloc.layout == FEMASM_MAT_AOS || mloc.layout == FEMASM_MAT_ELEMENT_SOA) ? mloc.e_ks : s.els;
   } else {
     mloc.layout = FEMASM_MAT_UNIFORM;
   }
@@ -1075,7 +1087,7 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
     if (!p->stage_b) HIPCHK(hipMalloc(&p->stage_b, (size_t)p->nrows * sizeof(double)));
     d_b = p->stage_b;
   }
-  p->gp_cur = (mloc.layout == FEMASM_MAT_AOS && p->kind != KIND_POISSON) ? mloc.gp : nullptr;
+  p->gp_cur = ((mloc.layout == FEMASM_MAT_AOS || mloc.layout == FEMASM_MAT_ELEMENT_SOA) && p->kind != KIND_POISSON) ? mloc.gp : nullptr;
   if (p->gp_cur && !is_device_ptr(mloc.gp)) {
     const int64_t eplane = (nsd == 3) ? (s.dim[0] - 1) * (s.dim[1] - 1) : (s.dim[0] - 1);
     const int64_t cnt = eplane * (s.ele - mloc.e_ks) * mloc.stride;
@@ -1308,14 +1320,16 @@ int femasm_assemble_interface(femasm_plan *p, const femasm_material *mat, const 
         return fail(FEMASM_ERR_ARG, "femasm_assemble_interface needs the material array in device memory");
       if (mloc.stride < need) return fail(FEMASM_ERR_ARG, "material stride %d < %d", mloc.stride, need);
       if (mloc.e_ks > p->s.els) return fail(FEMASM_ERR_ARG, "material starts above the first assembled element layer");
+    } else if (mloc.layout == FEMASM_MAT_ELEMENT_SOA) {
+      if (const char *why = check_element_soa(p, mloc)) return fail(FEMASM_ERR_ARG, "%s", why);
     } else if (mloc.layout != FEMASM_MAT_UNIFORM && !(mloc.layout == FEMASM_MAT_MANUFACTURED && p->kind == KIND_ELASTIC)) {
       return fail(FEMASM_ERR_ARG, "unknown material layout %d", mloc.layout);
     }
-    p->s.mat_e_ks = (mloc.layout == FEMASM_MAT_AOS) ? mloc.e_ks : p->s.els;
+    p->s.mat_e_ks = (mloc.layout == FEMASM_MAT_AOS || mloc.layout == FEMASM_MAT_ELEMENT_SOA) ? mloc.e_ks : p->s.els;
   } else {
     mloc.layout = FEMASM_MAT_UNIFORM;
   }
-  p->gp_cur = (mloc.layout == FEMASM_MAT_AOS && p->kind != KIND_POISSON) ? mloc.gp : nullptr;  // device memory (checked above)
+  p->gp_cur = ((mloc.layout == FEMASM_MAT_AOS || mloc.layout == FEMASM_MAT_ELEMENT_SOA) && p->kind != KIND_POISSON) ? mloc.gp : nullptr;  // device memory (checked above)
   const Slab &s = p->s;
   if (s.ks == 0) { p->iface_done = false; return FEMASM_OK; }  // lowest slab: nothing is owed, nothing carries over
   if (!p->send) return fail(FEMASM_ERR_ARG, "no send buffer");
@@ -1388,16 +1402,18 @@ int femasm_apply_operator(femasm_plan *p, const femasm_material *mat, const fema
       const int need = (p->kind == KIND_PLANE) ? 24 : 400;
       if (!mloc.gp || !is_device_ptr(mloc.gp) || mloc.stride < need || mloc.e_ks > p->s.els)
         return fail(FEMASM_ERR_ARG, "femasm_apply_operator needs a device material array covering the slab's elements");
+    } else if (mloc.layout == FEMASM_MAT_ELEMENT_SOA) {
+      if (const char *why = check_element_soa(p, mloc)) return fail(FEMASM_ERR_ARG, "%s", why);
     } else if (mloc.layout != FEMASM_MAT_UNIFORM && !(mloc.layout == FEMASM_MAT_MANUFACTURED && p->kind == KIND_ELASTIC)) {
       return fail(FEMASM_ERR_ARG, "unknown material layout %d", mloc.layout);
     }
-    p->s.mat_e_ks = (mloc.layout == FEMASM_MAT_AOS) ? mloc.e_ks : p->s.els;
+    p->s.mat_e_ks = (mloc.layout == FEMASM_MAT_AOS || mloc.layout == FEMASM_MAT_ELEMENT_SOA) ? mloc.e_ks : p->s.els;
   }
   if (!is_device_ptr(x) || !is_device_ptr(y)) return fail(FEMASM_ERR_ARG, "femasm_apply_operator works on device vectors");
   const Slab &s = p->s;
   RArgs a{};
   a.coords = p->coords;
-  p->gp_cur = (mloc.layout == FEMASM_MAT_AOS) ? mloc.gp : nullptr;
+  p->gp_cur = (mloc.layout == FEMASM_MAT_AOS || mloc.layout == FEMASM_MAT_ELEMENT_SOA) ? mloc.gp : nullptr;
   a.gp = p->gp_cur;
   a.elemF = p->elemF;
   a.cke = p->cke;

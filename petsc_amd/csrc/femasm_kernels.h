@@ -418,6 +418,9 @@ __global__ __launch_bounds__(256, 2) void k_assemble_rows(const Slab s, const KA
         const double *q = a.gp + emat * a.mat_stride;
         E = q[offE + p];
         nu = q[offNu + p];
+      } else if (a.mat_layout == 3) {  // FEMASM_MAT_ELEMENT_SOA: one (E, nu) per element, two planes
+        E = a.gp[emat];
+        nu = a.gp[a.mat_stride + emat];
       }
       scaled_coefs<KIND>(E, nu, wJ, r[NSD * NEN], r[NSD * NEN + 1], r[NSD * NEN + 2]);
     }
@@ -1229,6 +1232,9 @@ __global__ __launch_bounds__(256) void k_op_elem(const Slab s, const RArgs a, do
         const double *q = a.gp + emat * a.mat_stride;
         E = q[offE + p];
         nu = q[offNu + p];
+      } else if (a.mat_layout == 3) {  // FEMASM_MAT_ELEMENT_SOA
+        E = a.gp[emat];
+        nu = a.gp[a.mat_stride + emat];
       }
       double d11, d12, d44;
       scaled_coefs<KIND>(E, nu, wJ, d11, d12, d44);

@@ -201,8 +201,14 @@ __global__ __launch_bounds__(256, 2) void k_assemble_sweep(const Slab s, const K
     }
     const bool eok = exy_ok && L >= s.els && L < s.ele;
     const double *matq = nullptr;
+    double soaE = a.E, soaNu = a.nu;  // FEMASM_MAT_ELEMENT_SOA: the element's pair (else the uniform constants)
     if (eok && KIND != KIND_POISSON && a.mat_layout == 0)
       matq = a.gp + (gex + (M - 1) * (gey + (N - 1) * (L - s.mat_e_ks))) * a.mat_stride;
+    if (eok && KIND != KIND_POISSON && a.mat_layout == 3) {
+      const int64_t e = gex + (M - 1) * (gey + (N - 1) * (L - s.mat_e_ks));
+      soaE = a.gp[e];
+      soaNu = a.gp[a.mat_stride + e];
+    }
     __syncthreads();  // coordinates staged; the previous step's staged output has been read
 
     // One record, streamed: coordinates are read from LDS inside the J loop and every gradient pair is
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void k_assemble_sweep(const Slab s, const K
         dst[12 * SW_NS] = make_double2(wJ, 0.0);
         dst[13 * SW_NS] = make_double2(0.0, 0.0);
       } else {
-        double E = a.E, nu = a.nu;
+        double E = soaE, nu = soaNu;
         if (matq) { E = matq[96 + p]; nu = matq[104 + p]; }
         double d11, d12, d44;
         scaled_coefs<KIND>(E, nu, wJ, d11, d12, d44);
@@ -974,7 +980,8 @@ __global__ __launch_bounds__(64 * (3 + RowSweep<KIND>::NRW), 2) void k_assemble_
 
   // ------------------------------- record wave -------------------------------
   __builtin_amdgcn_s_setprio(3);  // its few memory instructions should not queue behind the row waves' stores
-  const bool aos = HASMAT && a.mat_layout == 0;
+  const bool soa = HASMAT && a.mat_layout == 3;  // FEMASM_MAT_ELEMENT_SOA: one (E, nu) per element, two planes
+  const bool aos = HASMAT && (a.mat_layout == 0 || soa);
   const int rw = wu - 3;  // record wave index: it takes the passes ps = rw (mod NRW)
   unsigned epoch2 = 0;
   auto record_waves_sync = [&](int ln) {
@@ -1022,7 +1029,12 @@ __global__ __launch_bounds__(64 * (3 + RowSweep<KIND>::NRW), 2) void k_assemble_
       const int e = ln + 64 * ps, my = e / NEX, mx = e - NEX * my;
       const int64_t mgx = i0 - 1 + mx, mgy = j0 - 1 + my;
       const bool ok = e < NEL && mgx >= 0 && mgx < M - 1 && mgy >= 0 && mgy < N - 1 && L >= s.els && L < s.ele;
-      if (ok) {
+      if (ok && soa) {
+        const int64_t eidx = mgx + (M - 1) * (mgy + (N - 1) * (L - s.mat_e_ks));
+        const double vE = a.gp[eidx], vNu = a.gp[a.mat_stride + eidx];
+#pragma unroll
+        for (int q = 0; q < 8; q++) mraw[ps][q] = vE, mraw[ps][8 + q] = vNu;
+      } else if (ok) {
         const double *mq = a.gp + (mgx + (M - 1) * (mgy + (N - 1) * (L - s.mat_e_ks))) * a.mat_stride + 96;
 #pragma unroll
         for (int q = 0; q < 16; q++) mraw[ps][q] = mq[q];
@@ -1383,7 +1395,8 @@ __global__ __launch_bounds__(64, SU_OCC) void k_assemble_s3_unit(const Slab s, c
   const int64_t ifirst = a.x0 + (int64_t)blockIdx.x * NU * SU_TX, j = a.y0 + blockIdx.y, kn = a.s0 + blockIdx.z;
   const int64_t gey = j + oy, L = kn - AS;
   const bool eok = L >= s.els && L < s.ele;
-  const bool aos = a.mat_layout == 0 && eok;
+  const bool soa = a.mat_layout == 3 && eok;  // FEMASM_MAT_ELEMENT_SOA: one (E, nu) per element, two planes
+  const bool aos = (a.mat_layout == 0 || a.mat_layout == 3) && eok;
   auto zline = [&](int64_t k) {
     const int64_t kc = k < s.cks ? s.cks : (k > a.cke - 1 ? a.cke - 1 : k);
     return a.coords[3 * (M * N * (kc - s.cks)) + 2];
@@ -1398,7 +1411,12 @@ __global__ __launch_bounds__(64, SU_OCC) void k_assemble_s3_unit(const Slab s, c
     const int nv = (a.x1 - i0 < SU_TX) ? (int)(a.x1 - i0) : SU_TX;
     const int64_t gex = i0 + (lx < nv ? lx : nv - 1) + ox;
     in.xa = a.coords[3 * gex], in.xb = a.coords[3 * (gex + 1)];
-    if (aos) {
+    if (soa) {
+      const int64_t eidx = gex + (M - 1) * (gey + (N - 1) * (L - s.mat_e_ks));
+      const double vE = a.gp[eidx], vNu = a.gp[a.mat_stride + eidx];
+#pragma unroll
+      for (int q = 0; q < 8; q++) in.m[q] = vE, in.m[8 + q] = vNu;
+    } else if (aos) {
       const double *mq = a.gp + (gex + (M - 1) * (gey + (N - 1) * (L - s.mat_e_ks))) * a.mat_stride + 96;
 #pragma unroll
       for (int q = 0; q < 16; q++) in.m[q] = mq[q];
@@ -1728,7 +1746,8 @@ __global__ __launch_bounds__(64) void k_assemble_e2_rect(const Slab s, const KAr
   // a.ends (E2:877-887: the nodes i = 0 and M-1 are Dirichlet): their rows sit right before and after the interior rows
   // of this node row; the first and last wave of the row write them with their run (unit rows), as k_assemble_p3_rect does
   const int pre = (a.ends && i0 == 1) ? END : 0, post = (a.ends && i0 + nvx == s.dim[0] - 1) ? END : 0;
-  const bool aos = a.mat_layout == 0;
+  const bool soa = a.mat_layout == 3;  // FEMASM_MAT_ELEMENT_SOA (never with FUSE: it carries no loads)
+  const bool aos = a.mat_layout == 0 || soa;
   const double xm = a.coords[2 * (i - 1)], xc = a.coords[2 * i], xp = a.coords[2 * (i + 1)];
   const double Jx[2] = {0.5 * (xc - xm), 0.5 * (xp - xc)};
   const double ax[2] = {1.0 / Jx[0], 1.0 / Jx[1]};
@@ -1742,6 +1761,13 @@ __global__ __launch_bounds__(64) void k_assemble_e2_rect(const Slab s, const KAr
     const int64_t Lc = L < s.els ? s.els : (L > s.ele - 1 ? s.ele - 1 : L);
 #pragma unroll
     for (int ox = 0; ox < 2; ox++) {
+      if (soa) {
+        const int64_t eidx = (i - 1 + ox) + (M - 1) * (Lc - s.mat_e_ks);
+        const double vE = a.gp[eidx], vNu = a.gp[a.mat_stride + eidx];
+#pragma unroll
+        for (int q = 0; q < 4; q++) m[ox][q] = vE, m[ox][4 + q] = vNu;
+        continue;
+      }
       const double *mq = a.gp + ((i - 1 + ox) + (M - 1) * (Lc - s.mat_e_ks)) * a.mat_stride + 8;
 #pragma unroll
       for (int q = 0; q < NM; q++) m[ox][q] = mq[q];

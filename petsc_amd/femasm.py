@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FEMASM_LIB", os.path.join(_HERE, "csrc", "libfemasm.so"))  # override: kernel experiments
 
 POISSON3D_Q1, PLANE_STRAIN2D_Q1, ELASTIC3D_Q1, ELASTIC3D_ENRICHED = 0, 1, 2, 3
-MAT_AOS, MAT_UNIFORM, MAT_MANUFACTURED = 0, 1, 2
+MAT_AOS, MAT_UNIFORM, MAT_MANUFACTURED, MAT_ELEMENT_SOA = 0, 1, 2, 3
 BC_NONE, BC_POISSON_INLOOP, BC_E2_COMPRESSION, BC_S3_ALLFACES_EXACT = 0, 1, 2, 3
 
 _TRAITS = {  # kind: (nsd, dof, nen, ngp)
@@ -194,11 +194,14 @@ class Plan:
         _check(load().femasm_plan_set_enriched_contraction(self._h, C.c_int(int(mode))))
 
     def assemble_system(self, values, b, material=None, bc=BC_NONE, E=0.0, nu=0.0, stride=0, e_ks=None,
-                        want_stats=False, enr_mode=0, symmetric=False, manufactured=False):
+                        want_stats=False, enr_mode=0, symmetric=False, manufactured=False, element_soa=False):
         """values / b: numpy (host) or torch (device) float64 buffers, or None.
-        material: AoS GaussPointCoefficients array (numpy/torch) or None for uniform E, nu."""
+        material: AoS GaussPointCoefficients array (numpy/torch) or None for uniform E, nu; with element_soa=True a
+        device tensor of two planes, E per element then nu per element, `stride` doubles apart (K only)."""
         if material is None:
             mat = Material(MAT_MANUFACTURED if manufactured else MAT_UNIFORM, 0, 0, None, E, nu)
+        elif element_soa:
+            mat = Material(MAT_ELEMENT_SOA, stride, self.els if e_ks is None else e_ks, _ptr(material), E, nu, 0, 0)
         else:
             mat = Material(MAT_AOS, stride, self.els if e_ks is None else e_ks, _ptr(material), E, nu, enr_mode, 0)
         bcs = BC(bc, 1 if symmetric else 0)
@@ -207,12 +210,12 @@ class Plan:
                                              C.byref(st) if want_stats else None))
         return st if want_stats else None
 
-    def assemble_interface(self, material=None, bc=BC_NONE, E=0.0, nu=0.0, stride=0, e_ks=None):
+    def assemble_interface(self, material=None, bc=BC_NONE, E=0.0, nu=0.0, stride=0, e_ks=None, element_soa=False):
         """First half of a split call: fill the send buffer only, asynchronously (see include/femasm.h)."""
         if material is None:
             mat = Material(MAT_UNIFORM, 0, 0, None, E, nu)
         else:
-            mat = Material(MAT_AOS, stride, self.els if e_ks is None else e_ks, _ptr(material), E, nu)
+            mat = Material(MAT_ELEMENT_SOA if element_soa else MAT_AOS, stride, self.els if e_ks is None else e_ks, _ptr(material), E, nu)
         bcs = BC(bc, 0)
         _check(load().femasm_assemble_interface(self._h, C.byref(mat), C.byref(bcs)))
 
@@ -235,12 +238,12 @@ class Plan:
         bcs = BC(bc, 1)
         _check(load().femasm_eliminate_columns(self._h, C.byref(bcs), _ptr(values), _ptr(b)))
 
-    def apply_operator(self, x, y, material=None, bc=BC_NONE, E=0.0, nu=0.0, stride=0, e_ks=None):
+    def apply_operator(self, x, y, material=None, bc=BC_NONE, E=0.0, nu=0.0, stride=0, e_ks=None, element_soa=False):
         """N4: y = K x matrix-free (device tensors; x on the plan's coordinate layers, y the owned rows)."""
         if material is None:
             mat = Material(MAT_UNIFORM, 0, 0, None, E, nu)
         else:
-            mat = Material(MAT_AOS, stride, self.els if e_ks is None else e_ks, _ptr(material), E, nu)
+            mat = Material(MAT_ELEMENT_SOA if element_soa else MAT_AOS, stride, self.els if e_ks is None else e_ks, _ptr(material), E, nu)
         bcs = BC(bc, 0)
         _check(load().femasm_apply_operator(self._h, C.byref(mat), C.byref(bcs), _ptr(x), _ptr(y)))
 

@@ -518,6 +518,58 @@ def test_s3_box_kernels_unit_and_rowsweep(env, monkeypatch, variant, dims):
     plan.close()
 
 
+@pytest.mark.parametrize("kind,dims", [("s3", (21, 7, 18)), ("s3", (6, 5, 4)), ("e2", (70, 19)), ("e2", (5, 4))])
+@pytest.mark.parametrize("mesh", ["uniform", "perturbed"])
+@pytest.mark.parametrize("variant", ["default", "rowsweep"])
+def test_element_soa_material_gives_the_same_k_as_the_records(env, monkeypatch, kind, dims, mesh, variant):
+    """FEMASM_MAT_ELEMENT_SOA (A14's compact form: E per element, then nu per element) against the AoS records that hold
+    the same pair at every Gauss point: the same K bit for bit, on the box kernels (both S3 ones), the general kernels and
+    the boundary rows; b holds the Dirichlet data only, as with a uniform material.  Also y = K x matrix-free."""
+    torch, F, dev = env["torch"], env["F"], env["dev"]
+    if variant == "rowsweep":
+        if kind != "s3" or mesh != "uniform":
+            pytest.skip("the row-sweep variant only differs for S3 boxes")
+        monkeypatch.setenv("FEMASM_S3_ROWSWEEP", "1")
+    case = make_case(env, kind, dims, perturb=(mesh == "perturbed"))
+    rng = np.random.default_rng(11)
+    st = case["stride"]
+    props = case["props"].reshape(-1, st).copy()
+    nel = props.shape[0]
+    Ee, nue = rng.uniform(50, 150, size=nel), rng.uniform(0.1, 0.4, size=nel)
+    oE, oN, ng = (96, 104, 8) if kind == "s3" else (8, 12, 4)
+    props[:, oE:oE + ng] = Ee[:, None]
+    props[:, oN:oN + ng] = nue[:, None]
+    dprops = torch.from_numpy(props.reshape(-1)).to(dev)
+    pad = 5                                            # plane distance larger than the element count
+    planes = torch.from_numpy(np.concatenate([Ee, np.zeros(pad), nue])).to(dev)
+    coords = torch.from_numpy(case["coords"]).to(dev)
+    plan = F.Plan(case["problem"], *case["dims"], coords=coords)
+    v_aos = torch.full((plan.nnz,), float("nan"), dtype=torch.float64, device=dev)
+    v_soa = torch.full((plan.nnz,), float("nan"), dtype=torch.float64, device=dev)
+    b_soa = torch.full((plan.nrows,), float("nan"), dtype=torch.float64, device=dev)
+    b_uni = torch.full((plan.nrows,), float("nan"), dtype=torch.float64, device=dev)
+    plan.assemble_system(v_aos, None, material=dprops, stride=st, bc=case["bc"])
+    lvl = plan.fast_path()
+    plan.assemble_system(v_soa, b_soa, material=planes, stride=nel + pad, bc=case["bc"], element_soa=True)
+    assert plan.fast_path() == lvl and lvl == (2 if mesh == "uniform" else 0)
+    assert not torch.isnan(v_soa).any()
+    assert torch.equal(v_aos, v_soa)
+    plan.assemble_system(None, b_uni, material=None, E=1.0, nu=0.3, bc=case["bc"])
+    assert torch.equal(b_soa, b_uni)
+    # matrix-free product
+    x = torch.from_numpy(rng.uniform(-1, 1, size=plan.nrows)).to(dev)
+    y1, y2 = torch.empty_like(x), torch.empty_like(x)
+    plan.apply_operator(x, y1, material=dprops, stride=st, bc=case["bc"])
+    plan.apply_operator(x, y2, material=planes, stride=nel + pad, bc=case["bc"], element_soa=True)
+    assert torch.equal(y1, y2)
+    # too small a plane distance, host planes: refused
+    with pytest.raises(F.FemasmError):
+        plan.assemble_system(v_soa, None, material=planes, stride=nel - 1, bc=case["bc"], element_soa=True)
+    with pytest.raises(F.FemasmError):
+        plan.assemble_system(v_soa, None, material=planes.cpu().numpy(), stride=nel + pad, bc=case["bc"], element_soa=True)
+    plan.close()
+
+
 @pytest.mark.parametrize("kernel", ["ke", "sweep"])
 @pytest.mark.parametrize("dims", [(33, 9, 21), (17, 5, 4), (4, 3, 5), (47, 12, 35)])
 def test_p3_general_kernels_element_matrix_and_node_row(env, monkeypatch, kernel, dims):
