@@ -570,6 +570,49 @@ def test_element_soa_material_gives_the_same_k_as_the_records(env, monkeypatch, 
     plan.close()
 
 
+@pytest.mark.parametrize("mesh", ["uniform", "perturbed"])
+def test_element_soa_material_on_an_upper_slab(env, mesh):
+    """FEMASM_MAT_ELEMENT_SOA on the upper of two slabs (planes that start at the slab's first element layer, e_ks):
+    the slab's rows and the rows it owes to the rank below (send buffer) are the bits the AoS records give."""
+    torch, F, dev, O, slab = env["torch"], env["F"], env["dev"], env["O"], env["slab"]
+    M, N, P = 19, 6, 11
+    coords = O.uniform_coords(3, M, N, P)
+    if mesh == "perturbed":
+        coords = O.perturb_coords(coords, 3, M, N, P)
+    plane_e = (M - 1) * (N - 1)
+    rng = np.random.default_rng(3)
+    nel = plane_e * (P - 1)
+    Ee, nue = rng.uniform(50, 150, size=nel), rng.uniform(0.1, 0.4, size=nel)
+    props = O.props_s3(M - 1, N - 1, P - 1, coords).reshape(-1, 400)
+    props[:, 96:104] = Ee[:, None]
+    props[:, 104:112] = nue[:, None]
+    (_, _), (ks, ke) = slab.slab_ranges(P, 2)
+    cks, cke = ks - 1, P
+    els, ele = slab.element_range(ks, ke)
+    co = torch.from_numpy(coords.reshape(P, -1)[cks:cke].reshape(-1).copy()).to(dev)
+    plan = F.Plan(F.ELASTIC3D_Q1, M, N, P, coords=co, ks=ks, ke=ke, cks=cks, cke=cke)
+    (_, sc), _ = plan.interface_buffers()
+    send = torch.zeros(sc, dtype=torch.float64, device=dev)
+    plan.interface_set_buffers(send, None)
+    aos = torch.from_numpy(props[els * plane_e:ele * plane_e].reshape(-1).copy()).to(dev)
+    held = (ele - els) * plane_e
+    planes = torch.from_numpy(np.concatenate([Ee[els * plane_e:ele * plane_e], nue[els * plane_e:ele * plane_e]])).to(dev)
+    out = []
+    for mat, kw in ((aos, dict(stride=400)), (planes, dict(stride=held, element_soa=True))):
+        v = torch.full((plan.nnz,), float("nan"), dtype=torch.float64, device=dev)
+        send.zero_()
+        plan.assemble_interface(material=mat, bc=F.BC_S3_ALLFACES_EXACT, e_ks=els, **kw)
+        plan.assemble_system(v, None, material=mat, bc=F.BC_S3_ALLFACES_EXACT, e_ks=els, **kw)
+        plan.sync()
+        out.append((v.clone(), send.clone()))
+    assert not torch.isnan(out[1][0]).any()
+    nk = sc - 3 * M * N     # the send buffer ends with the layer's b slice, which only the records can fill (loads)
+    assert torch.equal(out[0][0], out[1][0])
+    assert torch.equal(out[0][1][:nk], out[1][1][:nk])
+    assert out[0][1][:nk].abs().max() > 0
+    plan.close()
+
+
 @pytest.mark.parametrize("kernel", ["ke", "sweep"])
 @pytest.mark.parametrize("dims", [(33, 9, 21), (17, 5, 4), (4, 3, 5), (47, 12, 35)])
 def test_p3_general_kernels_element_matrix_and_node_row(env, monkeypatch, kernel, dims):
