@@ -413,14 +413,14 @@ __global__ __launch_bounds__(256, 2) void k_assemble_rows(const Slab s, const KA
       r[NSD * NEN] = wJ;
     } else {
       double E = a.E, nu = a.nu;
-      if (a.mat_layout == 0) {
+      if (a.mat_layout == 0 || a.mat_layout == 3) {
+        // the element's record (AoS: E[p], nu[p] at offE, offNu) or its entry in the E plane of FEMASM_MAT_ELEMENT_SOA
+        // (nu one plane distance further); one address computation for both, no extra live registers
         constexpr int offE = (KIND == KIND_PLANE) ? 8 : 96, offNu = (KIND == KIND_PLANE) ? 12 : 104;
-        const double *q = a.gp + emat * a.mat_stride;
-        E = q[offE + p];
-        nu = q[offNu + p];
-      } else if (a.mat_layout == 3) {  // FEMASM_MAT_ELEMENT_SOA: one (E, nu) per element, two planes
-        E = a.gp[emat];
-        nu = a.gp[a.mat_stride + emat];
+        const bool rec = a.mat_layout == 0;
+        const double *q = a.gp + emat * (rec ? a.mat_stride : 1);
+        E = q[rec ? offE + p : 0];
+        nu = q[rec ? offNu + p : a.mat_stride];
       }
       scaled_coefs<KIND>(E, nu, wJ, r[NSD * NEN], r[NSD * NEN + 1], r[NSD * NEN + 2]);
     }
@@ -1227,14 +1227,12 @@ __global__ __launch_bounds__(256) void k_op_elem(const Slab s, const RArgs a, do
       for (int n = 0; n < 8; n++) F[n] += wJ * (g[n][0] * gu[0] + g[n][1] * gu[1] + g[n][2] * gu[2]);
     } else {
       double E = Eu, nu = nuu;
-      if (a.mat_layout == 0) {
+      if (a.mat_layout == 0 || a.mat_layout == 3) {  // AoS record, or the planes of FEMASM_MAT_ELEMENT_SOA
         constexpr int offE = (KIND == KIND_PLANE) ? 8 : 96, offNu = (KIND == KIND_PLANE) ? 12 : 104;
-        const double *q = a.gp + emat * a.mat_stride;
-        E = q[offE + p];
-        nu = q[offNu + p];
-      } else if (a.mat_layout == 3) {  // FEMASM_MAT_ELEMENT_SOA
-        E = a.gp[emat];
-        nu = a.gp[a.mat_stride + emat];
+        const bool rec = a.mat_layout == 0;
+        const double *q = a.gp + emat * (rec ? a.mat_stride : 1);
+        E = q[rec ? offE + p : 0];
+        nu = q[rec ? offNu + p : a.mat_stride];
       }
       double d11, d12, d44;
       scaled_coefs<KIND>(E, nu, wJ, d11, d12, d44);

@@ -200,15 +200,9 @@ __global__ __launch_bounds__(256, 2) void k_assemble_sweep(const Slab s, const K
       for (int d = 0; d < 3; d++) sh_x[3 * q + d] = a.coords[3 * node + d];
     }
     const bool eok = exy_ok && L >= s.els && L < s.ele;
-    const double *matq = nullptr;
-    double soaE = a.E, soaNu = a.nu;  // FEMASM_MAT_ELEMENT_SOA: the element's pair (else the uniform constants)
-    if (eok && KIND != KIND_POISSON && a.mat_layout == 0)
-      matq = a.gp + (gex + (M - 1) * (gey + (N - 1) * (L - s.mat_e_ks))) * a.mat_stride;
-    if (eok && KIND != KIND_POISSON && a.mat_layout == 3) {
-      const int64_t e = gex + (M - 1) * (gey + (N - 1) * (L - s.mat_e_ks));
-      soaE = a.gp[e];
-      soaNu = a.gp[a.mat_stride + e];
-    }
+    const double *matq = nullptr;  // the element's record (AoS) or its entry in the E plane (FEMASM_MAT_ELEMENT_SOA)
+    if (eok && KIND != KIND_POISSON && (a.mat_layout == 0 || a.mat_layout == 3))
+      matq = a.gp + (gex + (M - 1) * (gey + (N - 1) * (L - s.mat_e_ks))) * (a.mat_layout == 0 ? a.mat_stride : 1);
     __syncthreads();  // coordinates staged; the previous step's staged output has been read
 
     // One record, streamed: coordinates are read from LDS inside the J loop and every gradient pair is
@@ -250,8 +244,12 @@ __global__ __launch_bounds__(256, 2) void k_assemble_sweep(const Slab s, const K
         dst[12 * SW_NS] = make_double2(wJ, 0.0);
         dst[13 * SW_NS] = make_double2(0.0, 0.0);
       } else {
-        double E = soaE, nu = soaNu;
-        if (matq) { E = matq[96 + p]; nu = matq[104 + p]; }
+        double E = a.E, nu = a.nu;
+        if (matq) {
+          const bool rec = a.mat_layout == 0;
+          E = matq[rec ? 96 + p : 0];
+          nu = matq[rec ? 104 + p : a.mat_stride];
+        }
         double d11, d12, d44;
         scaled_coefs<KIND>(E, nu, wJ, d11, d12, d44);
         dst[12 * SW_NS] = make_double2(d11, d12);
@@ -1746,7 +1744,7 @@ __global__ __launch_bounds__(64) void k_assemble_e2_rect(const Slab s, const KAr
   // a.ends (E2:877-887: the nodes i = 0 and M-1 are Dirichlet): their rows sit right before and after the interior rows
   // of this node row; the first and last wave of the row write them with their run (unit rows), as k_assemble_p3_rect does
   const int pre = (a.ends && i0 == 1) ? END : 0, post = (a.ends && i0 + nvx == s.dim[0] - 1) ? END : 0;
-  const bool soa = a.mat_layout == 3;  // FEMASM_MAT_ELEMENT_SOA (never with FUSE: it carries no loads)
+  const bool soa = !FUSE && a.mat_layout == 3;  // FEMASM_MAT_ELEMENT_SOA (never with FUSE: it carries no loads)
   const bool aos = a.mat_layout == 0 || soa;
   const double xm = a.coords[2 * (i - 1)], xc = a.coords[2 * i], xp = a.coords[2 * (i + 1)];
   const double Jx[2] = {0.5 * (xc - xm), 0.5 * (xp - xc)};
