@@ -469,7 +469,6 @@ __global__ __launch_bounds__(64 * EnrNodeCfg<S>::NW) void k_enr_node(const Slab 
   const int e = lane >> 3, b = lane & 7;  // phase 1: Gauss point p = b
   const int ox = (e & 1) - 1, oy = ((e >> 1) & 1) - 1, oz = (e >> 2) - 1;
   const int arow = 4 * (-oz) + ((-ox) == 0 ? ((-oy) == 0 ? 0 : 1) : ((-oy) == 0 ? 3 : 2));  // hex_idx(-ox, -oy, -oz)
-  const int bI = (b >> 1) & 1, bJ = ((b + 1) >> 1) & 1, bK = b >> 2;  // HDI, HDJ, HDK of the column node
   // node-independent decode of the reduction rounds: position u = lane + 64 it of an element's 8 x 9 S staged values
   int rd_r[NIT], rd_tc[NIT], rd_bI[NIT], rd_bJ[NIT], rd_bK[NIT];
 #pragma unroll
