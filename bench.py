@@ -373,7 +373,8 @@ def main():
             kernel = (f"k_enr_node<S={1 + args.n_enr}>" if mode == "node" else
                       f"k_enr_elem<S={1 + args.n_enr},{mode}> + k_enr_gather (all of K)")
         elif wl == "elastic2d":
-            kernel = "k_assemble_e2_rect" if level == 2 else "k_assemble_rows<PLANE_STRAIN2D>"
+            kernel = ("k_assemble_e2_rect" if level == 2 else
+                      "k_assemble_rows<PLANE_STRAIN2D>" if os.environ.get("FEMASM_E2_BRICK") else "k_assemble_ke_e2")
         else:
             kname = "ELASTIC3D" if wl == "elastic3d" else "POISSON3D"
             fast = (level == 2) if wl == "elastic3d" else (level >= 1)

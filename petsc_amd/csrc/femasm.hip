@@ -330,6 +330,26 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
       if (!rc2 && s1 == N && N - 1 >= s0 && N > 1) rc2 = launch_brick<KIND>(p, mat, bc, out, Box{0, M, 0, 1, N - 1, N}, s0, iface);
       return rc2;
     }
+    if (KIND == KIND_PLANE && !iface && M > 2 && y1 > y0 && !getenv("FEMASM_E2_BRICK")) {
+      // general quadrilaterals: interior nodes through the element-matrix kernel, the four edges of the node grid through
+      // the brick kernel (FEMASM_E2_BRICK=1: the brick kernel for everything, as in round 1, for A/B)
+      const Box b{1, M - 1, 0, 1, y0, y1};
+      const KArgs a = make_kargs<KIND>(p, mat, bc, out, b, s0, iface);
+      dim3 grid((unsigned)((b.x1 - b.x0 + KE2_TX - 1) / KE2_TX), (unsigned)((y1 - y0 + KE2_TY - 1) / KE2_TY), 1);
+      if (timed) HIPCHK(hipEventRecord(p->ev[4], p->stream));
+      hipLaunchKernelGGL(k_assemble_ke_e2, grid, dim3(128), 0, p->stream, p->s, a);
+      HIPCHK(hipGetLastError());
+      if (timed) {
+        HIPCHK(hipEventRecord(p->ev[5], p->stream));
+        const double nint = (double)(M - 2) * (double)(y1 - y0);
+        p->bytes_main = 8.0 * nint * 36.0 + 8.0 * T::NSD * p->nnodes + (aos2 ? 16.0 * T::NGP * p->nel : 0.0);
+      }
+      int rc2 = launch_brick<KIND>(p, mat, bc, out, Box{0, 1, 0, 1, y0, y1}, s0, iface);
+      if (!rc2) rc2 = launch_brick<KIND>(p, mat, bc, out, Box{M - 1, M, 0, 1, y0, y1}, s0, iface);
+      if (!rc2 && s0 == 0) rc2 = launch_brick<KIND>(p, mat, bc, out, Box{0, M, 0, 1, 0, 1}, s0, iface);
+      if (!rc2 && s1 == N && N - 1 >= s0 && N > 1) rc2 = launch_brick<KIND>(p, mat, bc, out, Box{0, M, 0, 1, N - 1, N}, s0, iface);
+      return rc2;
+    }
     if (timed) HIPCHK(hipEventRecord(p->ev[4], p->stream));
     const int rc2 = launch_brick<KIND>(p, mat, bc, out, Box{0, M, 0, 1, s0, s1}, s0, iface);
     if (timed) {

@@ -1942,6 +1942,176 @@ __global__ __launch_bounds__(64) void k_assemble_e2_rect(const Slab s, const KAr
 
 
 // ---------------------------------------------------------------------------
+// E2 on general quadrilaterals (level 0), element matrices through LDS: k_assemble_ke_e2 -- the 2-D sibling of
+// k_assemble_ke_p3.  The brick kernel forms every 2 x 2 block of an element in the rows of both of its nodes and
+// rebuilds the Gauss-point records of an element for each of its four nodes (~2 400 instructions per node row); here a
+// thread forms ONE element: its four Gauss-point records and the ten unique node-pair blocks (a <= b) of its element
+// matrix -- 36 numbers in LDS: a diagonal block (a, a) is symmetric, its K10 is stored as K01 (the two differ by the
+// rounding of (d12 g0) g1 against (d12 g1) g0 where each is formed on its own) -- and the node rows pick their blocks
+// (transposed for a > b) out of LDS.
+//   tile      15 x 7 interior nodes = 16 x 8 = 128 elements, 128 threads; thread = element, then thread = node
+//   stores    the tile's rows are 15-node runs of the CSR array (36 values per node): staged in HBM order in the
+//             element-matrix area (dead by then) and written as 16 B per thread from the 128-byte boundary below
+// Same arithmetic per Gauss point as the brick kernel (jac2, scaled_coefs, add_block); sums are formed per element
+// and then over the elements -- the reference's own order -- so the last bit can differ from the brick kernel.
+// ---------------------------------------------------------------------------
+constexpr int KE2_TX = 15, KE2_TY = 7, KE2_NK = 36, KE2_KS = 37;  // 37: odd stride, and four workgroups fit a CU's LDS
+struct Ke2Pairs { int off[4][4]; };  // first of the 4 numbers of block (a, b), a < b; of the 3 (K00, K01, K11) of block (a, a)
+constexpr Ke2Pairs make_ke2_pairs() {
+  Ke2Pairs o{};
+  int n = 0;
+  for (int a = 0; a < 4; a++)
+    for (int b = a; b < 4; b++) {
+      o.off[a][b] = o.off[b][a] = n;
+      n += (a == b) ? 3 : 4;
+    }
+  return o;
+}
+static_assert(make_ke2_pairs().off[3][3] + 3 == KE2_NK, "element matrix storage");
+__device__ const Ke2Pairs KE2_PAIRS = make_ke2_pairs();
+
+__global__ __launch_bounds__(128) void k_assemble_ke_e2(const Slab s, const KArgs a) {
+  constexpr int XS = KE2_TX + 2, YS = KE2_TY + 2, NB = RS2_NB, RUN = KE2_TX * NB;
+  __shared__ double sh_x[XS * YS * 2];
+  __shared__ __attribute__((aligned(16))) double sh_ke[128 * KE2_KS];  // element matrices; then the tile's rows in HBM order
+  static_assert(KE2_TY * RUN <= 128 * KE2_KS, "the staged rows alias the element matrices");
+  const int tid = threadIdx.x;
+  const int lx = tid & 15, ly = tid >> 4;  // element (ex, ey) of the halo'd tile / node of the tile (lx < 15, ly < 7)
+  const int64_t M = s.dim[0], N = s.dim[1];
+  const int64_t i0 = a.x0 + (int64_t)blockIdx.x * KE2_TX, j0 = a.s0 + (int64_t)blockIdx.y * KE2_TY;
+  const int nvx = (a.x1 - i0 < KE2_TX) ? (int)(a.x1 - i0) : KE2_TX;
+  const int nvy = (a.s1 - j0 < KE2_TY) ? (int)(a.s1 - j0) : KE2_TY;
+  for (int q = tid; q < XS * YS; q += 128) {  // node coordinates of the halo'd tile (clamped reads)
+    const int cy = q / XS, cx = q - XS * cy;
+    int64_t gi = i0 - 1 + cx, gj = j0 - 1 + cy;
+    gi = gi < 0 ? 0 : (gi > M - 1 ? M - 1 : gi);
+    gj = gj < s.cks ? s.cks : (gj > a.cke - 1 ? a.cke - 1 : gj);
+    const int64_t node = gi + M * (gj - s.cks);
+    sh_x[2 * q] = a.coords[2 * node];
+    sh_x[2 * q + 1] = a.coords[2 * node + 1];
+  }
+  __syncthreads();
+  {  // thread = element: records of the four Gauss points, the ten blocks (a <= b) of the element matrix
+    const int64_t gex = i0 - 1 + lx, gey = j0 - 1 + ly;
+    const bool eok = gex >= 0 && gex < M - 1 && gey >= 0 && gey < N - 1 && gey >= s.els && gey < s.ele;
+    double ke[KE2_NK];
+#pragma unroll
+    for (int q = 0; q < KE2_NK; q++) ke[q] = 0.0;
+    if (eok) {
+      double xc[8];
+#pragma unroll
+      for (int n = 0; n < 4; n++) {
+        const int cn = (lx + QDI[n]) + XS * (ly + QDJ[n]);
+        xc[2 * n] = sh_x[2 * cn];
+        xc[2 * n + 1] = sh_x[2 * cn + 1];
+      }
+      const int64_t emat = gex + (M - 1) * (gey - s.mat_e_ks);
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        const double(*G)[4] = c_tab2.G[p];
+        const Jac2 jj = jac2(G, xc);
+        double r[8];
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+          r[2 * n] = G[0][n] * jj.i00 + G[1][n] * jj.i01;
+          r[2 * n + 1] = G[0][n] * jj.i10 + G[1][n] * jj.i11;
+        }
+        const double wJ = 1.0 * jj.det;
+        if (!(wJ > 0.0)) atomicAdd(a.bad, 1ULL);
+        double E = a.E, nu = a.nu;
+        if (a.mat_layout == 0 || a.mat_layout == 3) {  // AoS record, or the planes of FEMASM_MAT_ELEMENT_SOA
+          const bool rec = a.mat_layout == 0;
+          const double *q = a.gp + emat * (rec ? a.mat_stride : 1);
+          E = q[rec ? 8 + p : 0];
+          nu = q[rec ? 12 + p : a.mat_stride];
+        }
+        double d11, d12, d44;
+        scaled_coefs<KIND_PLANE>(E, nu, wJ, d11, d12, d44);
+#pragma unroll
+        for (int na = 0; na < 4; na++) {
+          const double ga[2] = {r[2 * na], r[2 * na + 1]};
+          const double l[2] = {d12 * ga[0], d12 * ga[1]}, m[2] = {d44 * ga[0], d44 * ga[1]}, q[2] = {d11 * ga[0], d11 * ga[1]};
+          {  // block (a, a): the entries (0,0), (0,1), (1,1) of add_block
+            double *kd = ke + KE2_PAIRS.off[na][na];
+            kd[0] = fma(m[1], ga[1], fma(q[0], ga[0], kd[0]));
+            kd[1] = fma(m[1], ga[0], fma(l[0], ga[1], kd[1]));
+            kd[2] = fma(m[0], ga[0], fma(q[1], ga[1], kd[2]));
+          }
+#pragma unroll
+          for (int nb = na + 1; nb < 4; nb++) {
+            const double gb[2] = {r[2 * nb], r[2 * nb + 1]};
+            add_block<KIND_PLANE, 2>(ke + KE2_PAIRS.off[na][nb], l, m, q, gb);
+          }
+        }
+      }
+    }
+    double *dst = sh_ke + tid * KE2_KS;
+#pragma unroll
+    for (int q = 0; q < KE2_NK; q++) dst[q] = ke[q];
+  }
+  __syncthreads();  // element matrices complete
+  double acc[2][RS2_ROW];
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int q = 0; q < RS2_ROW; q++) acc[c][q] = 0.0;
+  const bool mynode = lx < nvx && ly < nvy;
+  {
+    const int glx = mynode ? lx : 0, gly = mynode ? ly : 0;
+#pragma unroll
+    for (int oy = -1; oy <= 0; oy++)
+#pragma unroll
+      for (int ox = -1; ox <= 0; ox++) {
+        const double *kp = sh_ke + ((glx + 1 + ox) + 16 * (gly + 1 + oy)) * KE2_KS;
+        const int ia = quad_idx(-ox, -oy);
+#pragma unroll
+        for (int by = 0; by <= 1; by++)
+#pragma unroll
+          for (int bx = 0; bx <= 1; bx++) {
+            const int ib = quad_idx(bx, by);
+            const int t = (oy + by + 1) * 3 + (ox + bx + 1);
+            const double *blk = kp + KE2_PAIRS.off[ia][ib];
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+              for (int cc = 0; cc < 2; cc++) {  // block (a, b) is stored for a < b, (b, a) is its transpose; (a, a): K00 K01 K11
+                const double v = (ia == ib) ? blk[c + cc] : (ia < ib ? blk[2 * c + cc] : blk[2 * cc + c]);
+                acc[c][2 * t + cc] = acc[c][2 * t + cc] + v;
+              }
+          }
+      }
+  }
+  __syncthreads();  // every thread has read its element matrices: the staged rows alias them
+  if (mynode) {
+    double2 *dst = reinterpret_cast<double2 *>(sh_ke + ly * RUN + lx * NB);
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int q = 0; q < RS2_ROW / 2; q++) dst[c * (RS2_ROW / 2) + q] = make_double2(acc[c][2 * q], acc[c][2 * q + 1]);
+  }
+  __syncthreads();
+  const int n = nvx * NB;
+  for (int rr = 0; rr < nvy; rr++) {  // one 15-node run per tile row, 16 B per thread from the 128-byte boundary below it
+    const double *stage = sh_ke + rr * RUN;
+    double *runp = a.out + (row_start(s, i0, j0 + rr, 0, 0) - a.base_off);
+    const int head = (int)((reinterpret_cast<uintptr_t>(runp) & 127) >> 3);
+    const int nchunk = (head + n + 1) >> 1;
+    constexpr int NIT = (RUN / 2 + 8 + 127) / 128;
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int q = tid + 128 * it, s0 = 2 * q - head;
+      if (q < nchunk) {
+        const int sa = s0 < 0 ? 0 : s0, sb = s0 + 1 < n ? s0 + 1 : n - 1;
+        const double2 v = make_double2(stage[sa], stage[sb]);
+        if (s0 >= 0 && s0 + 1 < n) store_pair(runp + s0, v);
+        else if (s0 == -1) runp[0] = v.y;
+        else if (s0 == n - 1) runp[s0] = v.x;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Dirichlet rows (A10/A11): one workgroup per x-row of nodes (j,k), one wave per Dirichlet node at a time; the
 // lanes write the node's dof rows (contiguous in the CSR array) as consecutive values.  Rows that are not on a
 // y/z face only have their two end nodes to do.

@@ -16,7 +16,7 @@ DOM = {
     "elastic3d_manufactured": ("elastic3d", "manufactured", ["k_assemble_s3_unit"], "k_assemble_s3_unit", 128),
     "elastic3d_general": ("elastic3d", "general", ["k_assemble_sweep<2>"], "k_assemble_sweep<ELASTIC3D>", 128),
     "poisson3d_general": ("poisson3d", "general", ["k_assemble_ke_p3"], "k_assemble_ke_p3", 256),
-    "elastic2d_general": ("elastic2d", "general", ["k_assemble_rows<1>"], "k_assemble_rows<PLANE_STRAIN2D>", 2048),
+    "elastic2d_general": ("elastic2d", "general", ["k_assemble_ke_e2"], "k_assemble_ke_e2", 2048),
     "enriched3d": ("enriched3d", "default", ["k_enr_node<2>"], "k_enr_node<S=2>", 128),
     # the two-kernel form: all of K = element matrices + segmented reduction, bytes per launch PAIR times the launch
     # pairs of a step

@@ -570,6 +570,23 @@ def test_element_soa_material_gives_the_same_k_as_the_records(env, monkeypatch, 
     plan.close()
 
 
+@pytest.mark.parametrize("kernel", ["ke", "brick"])
+@pytest.mark.parametrize("dims", [(70, 19), (17, 9), (4, 3), (3, 40), (131, 37)])
+def test_e2_general_kernels_element_matrix_and_brick(env, monkeypatch, kernel, dims):
+    """Plane strain on general quadrilaterals has two kernels for the interior nodes: k_assemble_ke_e2 (default: the
+    ten unique 2 x 2 blocks of each element matrix formed once, node rows gathered from LDS; 15 x 7 node tiles) and the
+    brick kernel k_assemble_rows (FEMASM_E2_BRICK=1).  Both against the oracle, per-Gauss-point material, on perturbed
+    meshes whose extents are not multiples of the tile."""
+    case = make_case(env, "e2", dims, perturb=True, vary_material=True)
+    if kernel == "brick":
+        monkeypatch.setenv("FEMASM_E2_BRICK", "1")
+    plan, vals, gb = gpu_assemble(env, case)
+    assert plan.fast_path() == 0
+    assert not np.isnan(vals).any()
+    assert rel(vals, case["K"]) <= TOL and rel(gb, case["b"]) <= TOL
+    plan.close()
+
+
 @pytest.mark.parametrize("mesh", ["uniform", "perturbed"])
 def test_element_soa_material_on_an_upper_slab(env, mesh):
     """FEMASM_MAT_ELEMENT_SOA on the upper of two slabs (planes that start at the slab's first element layer, e_ks):
