@@ -1,6 +1,10 @@
-# E2 general geometry: element-matrix kernel (default) against the brick kernel (FEMASM_E2_BRICK=1)
+# E2 general geometry: element-matrix kernel (default) against the brick kernel (FEMASM_E2_BRICK=1) and other tile shapes
 run() { python -c "import json,sys; d=json.loads(sys.stdin.read()); print('step', round(d['ms_per_step'],4), 'K', round(d['roofline']['avg_launch_ms'],4), 'frac', round(d['roofline']['frac'],3))"; }
-for e in 0 1 0 1; do
-  if [ $e = 1 ]; then export FEMASM_E2_BRICK=1; else unset FEMASM_E2_BRICK; fi
-  echo -n "brick=$e: "; timeout -k 10 120 python -u bench.py --workload elastic2d --perturb --steps 20 --warmup 3 --no-cpu-baseline "$@" | run || exit 1
+B="python -u bench.py --workload elastic2d --perturb --steps 20 --warmup 3 --no-cpu-baseline"
+for r in 1 2; do
+for v in "" _t31 _t7; do
+  [ -f petsc_amd/csrc/libfemasm$v.so ] || continue
+  echo -n "lib '$v': "; FEMASM_LIB=$PWD/petsc_amd/csrc/libfemasm$v.so timeout -k 10 120 $B "$@" | run || exit 1
 done
+done
+echo -n "brick: "; FEMASM_E2_BRICK=1 timeout -k 10 120 $B "$@" | run
