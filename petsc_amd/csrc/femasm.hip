@@ -7,6 +7,7 @@
 #include "../../include/femasm.h"
 #include "femasm_kernels.h"
 #include "femasm_sweep.h"
+#include "femasm_hex.h"
 #include "femasm_enriched.h"
 
 #include <hipcub/hipcub.hpp>
@@ -206,7 +207,7 @@ int finish_pending(femasm_plan *p) {
   flags[0] = flags[1] = flags[2] = 0;
   HIPCHK(hipMemcpyAsync(flags, p->bad, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, p->stream));
   HIPCHK(hipStreamSynchronize(p->stream));
-  if (p->pending_fast && flags[1]) p->fast_level = 0;
+  if (p->pending_fast && flags[1]) p->fast_level = (p->kind != KIND_PLANE && p->fast_level == 2) ? 1 : 0;  // as the synchronous loop
   p->pending_fast = false;
   if (flags[2]) return fail(FEMASM_ERR_HIP, "internal: %llu wave hand-shakes of the row-sweep kernel timed out", flags[2]);
   if (flags[0]) return fail(FEMASM_ERR_GEOMETRY, "%llu Gauss points with non-positive or NaN det(J) (reported by the "
@@ -365,7 +366,7 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
     if (M > 2 && N > 2 && z1 > z0) {
       const Box b{1, M - 1, 1, N - 1, z0, z1};
       const KArgs a = make_kargs<KIND>(p, mat, bc, out, b, s0, iface);
-      const bool fast = (KIND == KIND_ELASTIC) ? (p->fast_level == 2) : (p->fast_level >= 1);
+      const bool fast = p->fast_level >= 1;  // 2: verified boxes; 1: P3 parallelepipeds, S3 any hexahedra with one (E, nu) each
       const bool timed = p->time_main && !iface;
       const bool rect = fast && p->fast_level == 2;  // level 2: geometry from three coordinate lines (launch_rect_check ran)
       if (timed) {
@@ -378,7 +379,45 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
                         (p->fast_level == 2 ? 0.0 : 8.0 * T::NSD * (double)M * N * (z1 - z0 + 2)) +
                         (aos3 ? 16.0 * T::NGP * (double)(M - 1) * (N - 1) * (z1 - z0 + 1) : 0.0);
       }
-      if (fast) {
+      if (fast && KIND == KIND_ELASTIC && !rect) {
+        // level 1 of the elastic kind: any hexahedra, the material taken out of the Gauss-point loop (femasm_hex.h).
+        const int64_t tiles = ((b.x1 - b.x0 + HX_TX - 1) / HX_TX) * ((b.y1 - b.y0 + HX_TY - 1) / HX_TY);
+        // node layers per workgroup: the chunking that wastes least -- a chunk of zc node layers sweeps zc + 1 element
+        // layers, and the last round of the 2 x CUs resident workgroups should be full
+        const int64_t nz = z1 - z0, resident = (int64_t)p->ncu;  // one 12-wave workgroup per CU
+        int64_t zc = nz;
+        double best = -1.0;
+        for (int64_t chunks = 1; chunks <= nz; chunks++) {
+          const int64_t c = (nz + chunks - 1) / chunks, rc = (nz + c - 1) / c;
+          if (c < 6 && chunks > 1) break;
+          const int64_t W = tiles * rc, rounds = (W + resident - 1) / resident;
+          const double eff = (double)W / (double)(rounds * resident) * (double)nz / (double)(nz + rc);
+          if (eff > best + 1e-9) { best = eff; zc = c; }
+        }
+#ifdef FEMASM_DEV
+        if (const char *e = getenv("FEMASM_ZC")) zc = atoi(e) > 0 ? atoi(e) : zc;
+#endif
+        KArgs az = a;
+        az.zc = (int32_t)zc;
+        dim3 grid((unsigned)((b.x1 - b.x0 + HX_TX - 1) / HX_TX), (unsigned)((b.y1 - b.y0 + HX_TY - 1) / HX_TY),
+                  (unsigned)((z1 - z0 + zc - 1) / zc));
+#if HX_EXP == 9
+        {
+          static bool once = false;
+          if (!once) {
+            once = true;
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_assemble_s3_hex, HX_NT, 0);
+            hipFuncAttributes fa;
+            (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_assemble_s3_hex));
+            fprintf(stderr, "[femasm hex] occupancy API: %d workgroups per CU; static LDS %zu B, regs %d; grid %u x %u x %u, zc %lld\n", nb,
+                    fa.sharedSizeBytes, fa.numRegs, grid.x, grid.y, grid.z, (long long)zc);
+          }
+        }
+#endif
+        hipLaunchKernelGGL(k_assemble_s3_hex, grid, dim3(HX_NT), 0, p->stream, p->s, az);
+        p->used_fast = true;
+      } else if (fast) {
         constexpr int TX = RowSweep<KIND>::TX, TY = RowSweep<KIND>::TY;
         // node layers per workgroup.  Row-sweep kernel (2 workgroups per CU resident): of 16 / 32 / 64 the one that
         // fills the last round of resident workgroups best, weighed against the ~2-layer prologue of a workgroup
@@ -959,6 +998,17 @@ int femasm_plan_destroy(femasm_plan *p) {
   if (!p) return FEMASM_OK;
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
+#if HX_EXP == 9
+  {  // phase clocks of k_assemble_s3_hex (profiling build): one workgroup, waves 0 and 4, summed over launches
+    unsigned long long t[32];
+    if (p->bad && hipMemcpy(t, p->bad, sizeof t, hipMemcpyDeviceToHost) == hipSuccess && t[24]) {
+      const char *nm[8] = {"record", "B1", "contract", "B2", "deposit", "B3", "store", "B4"};
+      fprintf(stderr, "[femasm hex phases] most workgroups seen together on one CU: %llu; cycles per step (steps %llu):", t[25], t[24]);
+      for (int q = 0; q < 8; q++) fprintf(stderr, " %s w0 %.0f w4 %.0f |", nm[q], (double)t[8 + q] / t[24], (double)t[16 + q] / t[24]);
+      fprintf(stderr, "\n");
+    }
+  }
+#endif
 #if FEMASM_EXP == 3
   {  // phase clocks of the row-sweep kernel (profiling build)
     unsigned long long t[32];
@@ -1237,7 +1287,7 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
     // element; Poisson level 1: parallelepiped elements).  The test failed somewhere: the plan drops
     // a level for good (Poisson 2 -> 1 -> 0, elastic 2 -> 0) and K is assembled again, overwriting
     // every value of the previous attempt.
-    p->fast_level = (p->kind == KIND_POISSON && p->fast_level == 2) ? 1 : 0;
+    p->fast_level = (p->kind != KIND_PLANE && p->fast_level == 2) ? 1 : 0;
     p->used_fast = false;
     HIPCHK(hipMemsetAsync(p->bad, 0, 3 * sizeof(unsigned long long), p->stream));
     rc = launch_rect_check(p);  // (only if the plan is still at level 2, which it is not)

@@ -324,7 +324,8 @@ def test_asynchronous_assembly_is_final_in_stream_order(env, kind, dims, perturb
     for _ in range(2):   # the second call starts by reading the first one's flags
         plan.assemble_system(vals, b, material=mat, stride=case["stride"], bc=case["bc"])
     plan.sync()
-    assert plan.fast_path() == (0 if perturb else 2)
+    # (a broken box premise leaves the elastic kind at level 1: any hexahedra with one (E, nu) per element)
+    assert plan.fast_path() == ((1 if kind == "s3" else 0) if perturb else 2)
     assert rel(vals.cpu().numpy(), case["K"]) <= TOL and rel(b.cpu().numpy(), case["b"]) <= TOL
     plan.close()
 
@@ -551,7 +552,7 @@ def test_element_soa_material_gives_the_same_k_as_the_records(env, monkeypatch, 
     plan.assemble_system(v_aos, None, material=dprops, stride=st, bc=case["bc"])
     lvl = plan.fast_path()
     plan.assemble_system(v_soa, b_soa, material=planes, stride=nel + pad, bc=case["bc"], element_soa=True)
-    assert plan.fast_path() == lvl and lvl == (2 if mesh == "uniform" else 0)
+    assert plan.fast_path() == lvl and lvl == (2 if mesh == "uniform" else (1 if kind == "s3" else 0))
     assert not torch.isnan(v_soa).any()
     assert torch.equal(v_aos, v_soa)
     plan.assemble_system(None, b_uni, material=None, E=1.0, nu=0.3, bc=case["bc"])
@@ -615,6 +616,10 @@ def test_element_soa_material_on_an_upper_slab(env, mesh):
     held = (ele - els) * plane_e
     planes = torch.from_numpy(np.concatenate([Ee[els * plane_e:ele * plane_e], nue[els * plane_e:ele * plane_e]])).to(dev)
     out = []
+    # (one call first: the plan settles on the kernel level this mesh allows, so that both layouts below run the same
+    # kernels -- levels differ in rounding, layouts must not differ at all)
+    plan.assemble_system(torch.empty(plan.nnz, dtype=torch.float64, device=dev), None, material=aos, stride=400,
+                         bc=F.BC_S3_ALLFACES_EXACT, e_ks=els)
     for mat, kw in ((aos, dict(stride=400)), (planes, dict(stride=held, element_soa=True))):
         v = torch.full((plan.nnz,), float("nan"), dtype=torch.float64, device=dev)
         send.zero_()
@@ -732,7 +737,7 @@ def test_sheared_mesh_elastic_falls_back_poisson_stays_fast(env):
     dims = (9, 9, 9)
     case = _s3_case_from_coords(env, dims, _sheared(O, *dims))
     plan, vals, b = gpu_assemble(env, case)
-    assert plan.fast_path() == 0  # parallelepipeds are not boxes
+    assert plan.fast_path() == 1  # parallelepipeds are not boxes: the hexahedron kernel (one material per element)
     assert rel(vals, case["K"]) <= TOL and rel(b, case["b"]) <= TOL
     plan.close()
     # Poisson's fast kernel takes any parallelepiped
@@ -747,11 +752,65 @@ def test_sheared_mesh_elastic_falls_back_poisson_stays_fast(env):
     plan.close()
 
 
+@pytest.mark.parametrize("dims", [(8, 7, 9), (14, 11, 6), (27, 10, 47), (9, 30, 5), (3, 3, 3), (45, 23, 36)])
+@pytest.mark.parametrize("material", ["uniform_records", "per_element", "uniform_args"])
+def test_s3_hexahedron_kernel_level_1(env, dims, material):
+    """k_assemble_s3_hex (femasm_hex.h): any hexahedra, one (E, nu) per element taken out of the Gauss-point loop.
+    Perturbed meshes whose extents are not multiples of its 6 x 4 node tile nor of its z chunks, material the same in
+    every record / different per element / passed as two numbers; the plan must stay at level 1 and K, b match the
+    oracle's per-Gauss-point loops (S3:450-518)."""
+    torch, F, dev, O = env["torch"], env["F"], env["dev"], env["O"]
+    M, N, P = dims
+    coords = O.perturb_coords(O.uniform_coords(3, M, N, P), 3, M, N, P)
+    rp, ci = O.pattern(3, 3, M, N, P)
+    props = O.props_s3(M - 1, N - 1, P - 1, coords).reshape(-1, 400)
+    if material == "per_element":
+        rng = np.random.default_rng(5)
+        nel = props.shape[0]
+        props[:, 96:104] = rng.uniform(50, 150, size=nel)[:, None]
+        props[:, 104:112] = rng.uniform(0.1, 0.4, size=nel)[:, None]
+    props = props.reshape(-1)
+    K, b = O.assemble_elastic3d(M, N, P, coords, props, rp, ci)
+    O.bc_s3(M, N, P, coords, rp, ci, K, b)
+    plan = F.Plan(F.ELASTIC3D_Q1, M, N, P, coords=torch.from_numpy(coords).to(dev))
+    plan.set_fast_path(1)
+    vals = torch.full((plan.nnz,), float("nan"), dtype=torch.float64, device=dev)
+    if material == "uniform_args":
+        plan.assemble_system(vals, None, material=None, E=90.0, nu=0.28, bc=F.BC_S3_ALLFACES_EXACT)
+    else:
+        gb = torch.full((plan.nrows,), float("nan"), dtype=torch.float64, device=dev)
+        plan.assemble_system(vals, gb, material=torch.from_numpy(props).to(dev), stride=400, bc=F.BC_S3_ALLFACES_EXACT)
+        assert rel(gb.cpu().numpy(), b) <= TOL
+    assert plan.fast_path() == 1
+    v = vals.cpu().numpy()
+    assert not np.isnan(v).any()
+    assert rel(v, K) <= TOL
+    # twice the same bits (fixed summation trees, no atomics on values)
+    v2 = torch.full((plan.nnz,), float("nan"), dtype=torch.float64, device=dev)
+    plan.assemble_system(v2, None, material=None if material == "uniform_args" else torch.from_numpy(props).to(dev),
+                         E=90.0, nu=0.28, stride=400, bc=F.BC_S3_ALLFACES_EXACT)
+    assert torch.equal(vals, v2)
+    plan.close()
+
+
+def test_s3_hexahedron_kernel_falls_back_on_per_gauss_point_material(env):
+    """Its premise (one (E, nu) per element) is tested bitwise on the records: a material that varies inside an element
+    drops the plan to the general kernel, whose K is then the result."""
+    O = env["O"]
+    dims = (9, 8, 7)
+    coords = O.perturb_coords(O.uniform_coords(3, *dims), 3, *dims)
+    case = _s3_case_from_coords(env, dims, coords, vary_material=True)
+    plan, vals, b = gpu_assemble(env, case)
+    assert plan.fast_path() == 0
+    assert rel(vals, case["K"]) <= TOL and rel(b, case["b"]) <= TOL
+    plan.close()
+
+
 @pytest.mark.parametrize("kind", ["p3", "s3", "e2"])
 def test_general_geometry_drops_to_the_general_kernel(env, kind):
     case = make_case(env, kind, (70, 40) if kind == "e2" else (8, 7, 9), perturb=True)
     plan, vals, b = gpu_assemble(env, case)
-    assert plan.fast_path() == 0
+    assert plan.fast_path() == (1 if kind == "s3" else 0)  # S3: hexahedra with one material each stay at level 1
     assert rel(vals, case["K"]) <= TOL
     plan.close()
 
@@ -763,7 +822,7 @@ def test_one_moved_interior_node_is_enough_to_fall_back(env):
     c[4 + 9 * (4 + 9 * 4)] += [0.01, -0.02, 0.015]
     case = _s3_case_from_coords(env, dims, c.reshape(-1).copy())
     plan, vals, b = gpu_assemble(env, case)
-    assert plan.fast_path() == 0
+    assert plan.fast_path() == 1
     assert rel(vals, case["K"]) <= TOL
     plan.close()
 
