@@ -48,6 +48,8 @@ def parse():
                     help="elastic3d: FEMASM_MAT_MANUFACTURED (f and grad u evaluated in the RHS kernel, constant E, nu) "
                          "instead of streaming the drivers' AoS records")
     ap.add_argument("--strong", action="store_true", help="fixed global mesh split over N slabs")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="femasm_plan_set_option (kernel variants / tile parameters for A/B runs), repeatable")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-general", action="store_true",
                     help="skip the general_geometry sub-record (the same mesh perturbed, timed after the main variant)")
@@ -348,6 +350,9 @@ def main():
                       n_enr=args.n_enr if wl == "enriched3d" else 0)
         plan.set_stream(torch.cuda.current_stream().cuda_stream)
         plan.set_fast_path(args.fast_level)
+        for kv in args.option:
+            name, _, value = kv.partition("=")
+            plan.set_option(name, int(value or 1))
         if wl == "enriched3d":
             if args.enr_contraction != "default":
                 plan.set_enriched_contraction({"valu": 0, "mfma": 1, "node": 2}[args.enr_contraction])

@@ -83,7 +83,11 @@ typedef struct {
   int32_t enr_mode;     /* FEMASM_ELASTIC3D_ENRICHED: 0 = SGFEM, phi = psi - I_h psi (`type` 1, R3:42);
                            1 = GFEM, phi = psi (`type` 0).  Record stride = 408 | 416 (R3:52-68 with 32- /
                            64-bit PetscInt) + 64 n_enr: per family psi at the 8 nodes, at the 8 Gauss points,
-                           grad psi at the 8 Gauss points [p][3], psi at the 24 face Gauss points    */
+                           grad psi at the 8 Gauss points [p][3], psi at the 24 face Gauss points.
+                           REQUIRED: the records of the (up to 8) elements around a node carry the same
+                           enrich_type / n_enrich for that node (the engine reads them from ONE of these elements,
+                           as R3's GetNodalRedundantDofs would); records that disagree give rows that differ between
+                           a one-plan and a slab assembly, and no error is raised                  */
   int32_t reserved;
 } femasm_material;
 
@@ -159,6 +163,23 @@ int femasm_plan_get_fast_path(femasm_plan *plan, int *level);
  *                          tile) into a scratch ring, then a deterministic segmented reduction per node
  * Measured on MI355X in DESIGN.md section 9.  Results differ by rounding only. */
 int femasm_plan_set_enriched_contraction(femasm_plan *plan, int mode);
+/* No counterpart in the reference.  Kernel variants and tile parameters that the engine otherwise chooses by itself,
+ * for A/B measurements and for the tests that keep the alternative kernels covered (DESIGN.md section 4 lists them).
+ * The library reads NOTHING from the environment: this call is the only way to leave the automatic choice.
+ * value 0 = automatic / off.  Names:
+ *   "zc"              node layers per workgroup of the row-sweep, P3 box and S3 hexahedron kernels
+ *   "s3_units"        x-consecutive units per wave of k_assemble_s3_unit
+ *   "e2_yc"           node rows per wave of k_assemble_e2_rect
+ *   "rhs_grid"        cap on the resident grid of the S3 right-hand-side pass
+ *   "enr_scratch_mb"  enriched kind, two-kernel form: size of the element-matrix ring
+ *   "s3_rowsweep"     1: elastic boxes through k_assemble_rowsweep<ELASTIC> instead of k_assemble_s3_unit
+ *   "p3_sweep"        1: Poisson on general hexahedra through the node-row kernel instead of k_assemble_ke_p3
+ *   "e2_brick"        1: plane strain on general quadrilaterals through the brick kernel for every row
+ *   "e2_two_pass"     1: plane strain on boxes, K and b in two passes
+ *   "enr_rhs_simple"  1: enriched kind, the per-element right-hand side
+ *   "debug"           1: launch facts on stderr
+ * Results differ by rounding at most (every variant is tested against the oracle). */
+int femasm_plan_set_option(femasm_plan *plan, const char *name, int64_t value);
 
 /* Sparsity pattern of the owned rows (A12): rowptr is local (starts at 0, int64 so
  * 256^3 elastic fits), colidx holds GLOBAL column ids (= PETSc natural numbering for
@@ -209,9 +230,11 @@ int femasm_assemble_interface(femasm_plan *plan, const femasm_material *material
 /* The exchange itself, for C/C++ MPI drivers (one rank per GPU): replaces what MatAssemblyBegin/End's stash and
  * DMLocalToGlobalBegin/End(ADD_VALUES) move (P3:345-346, 638-639; S3:710-711, 794-795).  comm is the caller's
  * ncclComm_t (RCCL; created with ncclCommInitRank from an id the driver broadcasts over MPI); one ncclSend of the send
- * buffer to rank_below and one ncclRecv of the receive buffer from rank_above, grouped, on the plan's stream -- after
- * femasm_assemble_interface (overlapped with the rest of the assembly) or after femasm_assemble_system.  Pass -1 where
- * there is no neighbour.  Returns without waiting; femasm_interface_apply, queued on the same stream, follows it.
+ * buffer to rank_below and one ncclRecv of the receive buffer from rank_above, grouped, on a communication stream the
+ * plan owns: it starts when the kernels queued on the plan's stream so far (femasm_assemble_interface, or all of
+ * femasm_assemble_system) have filled the send buffer, and what is queued on the plan's stream afterwards -- the bulk of
+ * the assembly -- does not wait for it.  Pass -1 where there is no neighbour.  Returns without waiting;
+ * femasm_interface_apply makes the plan's stream wait for the pair before it adds the received rows.
  * RCCL is looked up at run time (already loaded by the driver, or librccl.so): the library does not link against it. */
 int femasm_interface_exchange(femasm_plan *plan, void *comm, int rank_below, int rank_above);
 /* own + received, fixed order (deterministic); Dirichlet rows are left untouched. */
@@ -265,8 +288,10 @@ int femasm_error_integrals(femasm_plan *plan, const double *u, double sums[2]);
  * partial sums live in a static device array inside the library (1 MiB per GPU, held until the process ends) instead
  * of plan-owned memory, u and sums are DEVICE pointers (sums[2] is written in stream order, nothing is copied back
  * and the call does not wait), and no hipMalloc / hipFree / host copy happens.  Limit: at most 16 777 216 elements
- * (256^3) in the plan's slab, larger slabs are rejected with FEMASM_ERR_ARG.  All plans of one GPU share the one
- * array: calls that overlap on a GPU (different streams or host threads) race -- order them. */
+ * (256^3) in the plan's slab, larger slabs are rejected with FEMASM_ERR_ARG.  Every plan holds a slice of its GPU's
+ * array of its own from femasm_plan_create to femasm_plan_destroy (32 slots of 524 288 elements, first fit), so plans
+ * driven on different streams do not meet; a plan for which no slice is left is rejected with FEMASM_ERR_ARG (use
+ * femasm_error_integrals).  Calls on ONE plan that overlap (two streams, two host threads) still race -- order them. */
 int femasm_error_integrals_static(femasm_plan *plan, const double *u, double *sums);
 
 /* SURVEY 8(f) row N2, the step after the path: landing K in a (device-resident) PETSc Mat without the host.

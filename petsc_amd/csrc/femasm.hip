@@ -90,6 +90,32 @@ int static_scratch_for(int device, double **out) {
   if (out) *out = g_scratch_ptr[device];
   return FEMASM_OK;
 }
+// Every plan of a GPU gets a slice of that GPU's array of its own (first fit over 32 slots of 2048 workgroups' partial
+// sums), so that plans driven on different streams -- two slabs on one GPU -- never write the same words.  A plan whose
+// slab does not fit what is left gets none and femasm_error_integrals_static rejects it.
+constexpr int SCR_SLOTS = 32;
+constexpr int64_t SCR_SLOT_NB = STATIC_NB_MAX / SCR_SLOTS;
+uint32_t g_scratch_used[MAX_DEVICES] = {};
+int scratch_reserve(int device, int64_t nb, int *nslots) {
+  const int n = (int)((nb + SCR_SLOT_NB - 1) / SCR_SLOT_NB);
+  *nslots = 0;
+  if (n < 1 || n > SCR_SLOTS || device < 0 || device >= MAX_DEVICES) return -1;
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  const uint32_t mask = n == 32 ? 0xffffffffu : ((1u << n) - 1u);
+  for (int s0 = 0; s0 + n <= SCR_SLOTS; s0++)
+    if ((g_scratch_used[device] & (mask << s0)) == 0) {
+      g_scratch_used[device] |= mask << s0;
+      *nslots = n;
+      return s0;
+    }
+  return -1;
+}
+void scratch_release(int device, int slot, int nslots) {
+  if (slot < 0 || nslots <= 0 || device < 0 || device >= MAX_DEVICES) return;
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  const uint32_t mask = nslots == 32 ? 0xffffffffu : ((1u << nslots) - 1u);
+  g_scratch_used[device] &= ~(mask << slot);
+}
 }  // namespace
 
 namespace {
@@ -160,6 +186,11 @@ struct femasm_plan {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // femasm_interface_exchange: the send / receive pair runs on a stream of its own, so that the assembly kernels queued
+  // behind it on `stream` do not wait for the neighbours (ev_send: the send buffer is final; ev_xchg: the pair is done)
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_send = nullptr, ev_xchg = nullptr;
+  bool xchg_pending = false;           // femasm_interface_apply has to wait for ev_xchg
   int ncu = 256;                       // compute units of the device
   int rhs_wg_per_cu[2] = {0, 0};       // resident workgroups per CU of k_rhs_elem_elastic_runs<false / true>
   bool rect_checked = false;           // k_check_rectilinear ran on the stream in this call (its verdict is bad[3])
@@ -179,13 +210,30 @@ struct femasm_plan {
   int64_t partial_count = 0;
   double *stage_u = nullptr;           // femasm_error_integrals: device copy of a host solution vector
   int64_t stage_u_count = 0;
-  double *static_scratch = nullptr;    // this device's copy of the file-scope `scratch` array (femasm_error_integrals_static)
+  double *static_scratch = nullptr;    // this plan's slice of this device's copy of the file-scope `scratch` array
+  int static_slot = -1, static_nslots = 0;  // (femasm_error_integrals_static; null / -1: no slice was left for this plan)
 
   double *e2_bout = nullptr;           // E2 one-pass form: launch_K hands this b array to k_assemble_e2_rect ...
   int64_t e2_b0 = 0, e2_b1 = 0;        // ... which then wrote b of the node rows [e2_b0, e2_b1)
   bool async = false;                  // femasm_plan_set_async: assemble_system / interface_apply do not wait for the device
   bool pending = false;                // an asynchronous call has not had its flags read yet (femasm_plan_sync does it)
   bool pending_fast = false;           // ... and it used a fast kernel (premise flag bad[1] decides the plan's level)
+
+  // femasm_plan_set_option: kernel variants kept for A/B measurements and for the tests that keep them covered.
+  // All zero = the automatic choice; nothing here is read from the environment.
+  struct Options {
+    int64_t zc = 0;              // node layers per workgroup of the row-sweep / P3 rect / S3 hexahedron kernels
+    int64_t s3_units = 0;        // x-consecutive units per wave of k_assemble_s3_unit
+    int64_t e2_yc = 0;           // node rows per wave of k_assemble_e2_rect
+    int64_t rhs_grid = 0;        // cap on the resident grid of the S3 RHS pass
+    int64_t enr_scratch_mb = 0;  // enriched kind, two-kernel form: ring size
+    int s3_rowsweep = 0;         // elastic boxes: k_assemble_rowsweep<ELASTIC> instead of k_assemble_s3_unit
+    int p3_sweep = 0;            // P3 general: k_assemble_sweep_p3 instead of k_assemble_ke_p3
+    int e2_brick = 0;            // E2 general: the brick kernel for every row instead of k_assemble_ke_e2
+    int e2_two_pass = 0;         // E2 boxes: K and b in two passes
+    int enr_rhs_simple = 0;      // enriched kind: the per-element RHS
+    int debug = 0;               // prints launch facts to stderr
+  } opt;
 
   // config 5 (KIND_ENRICHED)
   int n_enr = 0;                       // enrichment families per node: dof = 3 (1 + n_enr)
@@ -300,14 +348,13 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
       KArgs a = make_kargs<KIND>(p, mat, bc, out, b, s0, iface);
       a.ends = (bc == FEMASM_BC_E2_COMPRESSION) ? 1 : 0;  // the kernel also writes the Dirichlet rows of the columns i = 0, M-1
       // one-pass form: b of these node rows from the same sweep over the records (AoS records with 16-byte alignment)
-      static const bool no_fuse = getenv("FEMASM_E2_TWO_PASS") != nullptr;
+      const bool no_fuse = p->opt.e2_two_pass != 0;
       if (p->e2_bout && a.ends && aos2 && !no_fuse && ((uintptr_t)p->e2_bout & 15) == 0) {
         a.bout = p->e2_bout;
         p->e2_b0 = y0;
         p->e2_b1 = y1;
       }
-      const char *yc_env = getenv("FEMASM_E2_YC");  // node rows per wave
-      a.zc = yc_env ? std::max(1, atoi(yc_env)) : E2W_YC;
+      a.zc = p->opt.e2_yc > 0 ? (int32_t)p->opt.e2_yc : E2W_YC;  // node rows per wave
       dim3 grid((unsigned)((b.x1 - b.x0 + RS2_TX - 1) / RS2_TX), (unsigned)((y1 - y0 + a.zc - 1) / a.zc), 1);
       if (timed) HIPCHK(hipEventRecord(p->ev[4], p->stream));
       if (a.bout) hipLaunchKernelGGL(k_assemble_e2_rect<true>, grid, dim3(64), 0, p->stream, p->s, a);
@@ -331,7 +378,7 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
       if (!rc2 && s1 == N && N - 1 >= s0 && N > 1) rc2 = launch_brick<KIND>(p, mat, bc, out, Box{0, M, 0, 1, N - 1, N}, s0, iface);
       return rc2;
     }
-    if (KIND == KIND_PLANE && !iface && M > 2 && y1 > y0 && !getenv("FEMASM_E2_BRICK")) {
+    if (KIND == KIND_PLANE && !iface && M > 2 && y1 > y0 && !p->opt.e2_brick) {
       // general quadrilaterals: interior nodes through the element-matrix kernel, the four edges of the node grid through
       // the brick kernel (FEMASM_E2_BRICK=1: the brick kernel for everything, as in round 1, for A/B)
       const Box b{1, M - 1, 0, 1, y0, y1};
@@ -394,9 +441,7 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
           const double eff = (double)W / (double)(rounds * resident) * (double)nz / (double)(nz + rc);
           if (eff > best + 1e-9) { best = eff; zc = c; }
         }
-#ifdef FEMASM_DEV
-        if (const char *e = getenv("FEMASM_ZC")) zc = atoi(e) > 0 ? atoi(e) : zc;
-#endif
+        if (p->opt.zc > 0) zc = p->opt.zc;
         KArgs az = a;
         az.zc = (int32_t)zc;
         dim3 grid((unsigned)((b.x1 - b.x0 + HX_TX - 1) / HX_TX), (unsigned)((b.y1 - b.y0 + HX_TY - 1) / HX_TY),
@@ -438,7 +483,7 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
             if (score > best) { best = score; zc = c; }
           }
         }
-        if (const char *e = getenv("FEMASM_ZC")) zc = atoi(e) > 0 ? atoi(e) : zc;
+        if (p->opt.zc > 0) zc = p->opt.zc;
         if (zc > 128) zc = 128;
         KArgs az = a;
         az.zc = (int32_t)zc;
@@ -449,14 +494,13 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
           dim3 grid((unsigned)((b.x1 - b.x0 + P3W_TX - 1) / P3W_TX), (unsigned)(b.y1 - b.y0),
                     (unsigned)((z1 - z0 + zc - 1) / zc));
           hipLaunchKernelGGL(k_assemble_p3_rect, grid, dim3(64), 0, p->stream, p->s, az);
-        } else if (KIND == KIND_ELASTIC && rect && !getenv("FEMASM_S3_ROWSWEEP") && b.y1 - b.y0 < 65536 && z1 - z0 < 65536) {
+        } else if (KIND == KIND_ELASTIC && rect && !p->opt.s3_rowsweep && b.y1 - b.y0 < 65536 && z1 - z0 < 65536) {
           // elastic on a rectilinear mesh: one-shot units (one wave = one 8-node run each) in memory order
           // (FEMASM_S3_ROWSWEEP=1: the persistent row-sweep kernel of round 1, for A/B)
           // x-consecutive units per wave: as many as leave >= 8192 waves (four rounds of the chip at two waves per SIMD);
           // at 128^3 a wave walks a whole line (measured: 1 unit 1.09 ms, 4: 1.04, 8: 1.00, 16: 0.91-0.93)
           const int64_t ux = (b.x1 - b.x0 + SU_TX - 1) / SU_TX, lines = (int64_t)(b.y1 - b.y0) * (z1 - z0);
-          const char *nu_env = getenv("FEMASM_S3_UNITS");
-          az.zc = (int32_t)(nu_env ? std::max(1, atoi(nu_env)) : std::max<int64_t>(1, std::min<int64_t>(ux, ux * lines / 8192)));
+          az.zc = (int32_t)(p->opt.s3_units > 0 ? p->opt.s3_units : std::max<int64_t>(1, std::min<int64_t>(ux, ux * lines / 8192)));
           const int64_t per = (int64_t)az.zc * SU_TX;
           dim3 grid((unsigned)((b.x1 - b.x0 + per - 1) / per), (unsigned)(b.y1 - b.y0), (unsigned)(z1 - z0));
           hipLaunchKernelGGL(k_assemble_s3_unit, grid, dim3(64), 0, p->stream, p->s, az);
@@ -469,7 +513,7 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
       } else {
         dim3 grid((unsigned)((b.x1 - b.x0 + SW_TX - 1) / SW_TX), (unsigned)((b.y1 - b.y0 + SW_TY - 1) / SW_TY),
                   (unsigned)((z1 - z0 + SW_ZC - 1) / SW_ZC));
-        if (KIND == KIND_POISSON && !getenv("FEMASM_P3_SWEEP")) {
+        if (KIND == KIND_POISSON && !p->opt.p3_sweep) {
           // element matrices through LDS (FEMASM_P3_SWEEP=1: the node-row kernel of round 1, for A/B)
           dim3 gke((unsigned)((b.x1 - b.x0 + KE_TX - 1) / KE_TX), (unsigned)((b.y1 - b.y0 + KE_TY - 1) / KE_TY),
                    (unsigned)((z1 - z0 + KE_ZC - 1) / KE_ZC));
@@ -604,11 +648,10 @@ int launch_rhs(femasm_plan *p, const femasm_material *mat, int bc, double *out, 
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu[0], k_rhs_elem_elastic_runs<false>, 64, 0));
         if (wg_per_cu[0] < 1) wg_per_cu[0] = 1;
         if (wg_per_cu[1] < 1) wg_per_cu[1] = 1;
-        if (getenv("FEMASM_DEBUG")) fprintf(stderr, "[femasm] rhs runs: ncu %d, workgroups per CU %d (general) %d (rect)\n", ncu, wg_per_cu[0], wg_per_cu[1]);
+        if (p->opt.debug) fprintf(stderr, "[femasm] rhs runs: ncu %d, workgroups per CU %d (general) %d (rect)\n", ncu, wg_per_cu[0], wg_per_cu[1]);
       }
       // FEMASM_RHS_GRID caps the grid (tests: several tasks per persistent wave on small meshes)
-      const char *cap_env = getenv("FEMASM_RHS_GRID");
-      const int64_t grid_cap = cap_env ? atoll(cap_env) : 0;
+      const int64_t grid_cap = p->opt.rhs_grid;
       auto grid = [&](int v) {
         int64_t r = (int64_t)ncu * wg_per_cu[v];
         if (grid_cap > 0 && grid_cap < r) r = grid_cap;
@@ -702,7 +745,7 @@ int assemble_enriched(femasm_plan *p, const femasm_material *mat, int bc, double
     // ring of element layers: as many as the scratch budget holds (FEMASM_ENR_SCRATCH_MB, default 3072), at least 2
     const bool two_phase = p->enr_mfma == 0 || p->enr_mfma == 1;  // else: one node-centric pass, no ring
     int64_t budget = 3072;
-    if (const char *e = getenv("FEMASM_ENR_SCRATCH_MB")) budget = atoll(e) > 0 ? atoll(e) : budget;
+    if (p->opt.enr_scratch_mb > 0) budget = p->opt.enr_scratch_mb;
     const int64_t layer_doubles = eplane * KE;
     int64_t nring = (budget << 20) / (layer_doubles * 8);
     if (nring > nlay + 1) nring = nlay + 1;
@@ -792,7 +835,7 @@ int assemble_enriched(femasm_plan *p, const femasm_material *mat, int bc, double
   if (stats) HIPCHK(hipEventRecord(p->ev[1], p->stream));
   if (b) {
     if (p->nel > 0) {
-      static const bool simple = getenv("FEMASM_ENR_RHS_SIMPLE") != nullptr;  // the thread-per-element statement of the formulas
+      const bool simple = p->opt.enr_rhs_simple != 0;  // the thread-per-element statement of the formulas
       if (simple) {
         const dim3 grid((unsigned)((p->nel + 127) / 128));
         switch (S) {
@@ -951,6 +994,12 @@ int femasm_plan_create(const femasm_mesh *mesh, const femasm_quad *quad, int dev
     p->coords = p->coords_dev;
   }
 
+  {  // this plan's slice of the static scratch (set-up of the no-allocation entry point)
+    double *base = p->static_scratch;
+    p->static_scratch = nullptr;
+    p->static_slot = scratch_reserve(device, (p->nel + 255) / 256, &p->static_nslots);
+    if (p->static_slot >= 0) p->static_scratch = base + 2 * SCR_SLOT_NB * p->static_slot;
+  }
   PCHK(hipMalloc(&p->rowptr, (p->nrows + 1) * sizeof(int64_t)));
   PCHK(hipMalloc(&p->colidx, (size_t)(p->nnz > 0 ? p->nnz : 1) * sizeof(int32_t)));
   {
@@ -1027,6 +1076,13 @@ int femasm_plan_destroy(femasm_plan *p) {
   if (p->flags_host) (void)hipHostFree(p->flags_host);
   for (auto &e : p->ev)
     if (e) (void)hipEventDestroy(e);
+  scratch_release(p->device, p->static_slot, p->static_nslots);
+  if (p->comm_stream) {
+    (void)hipStreamSynchronize(p->comm_stream);
+    (void)hipStreamDestroy(p->comm_stream);
+  }
+  if (p->ev_send) (void)hipEventDestroy(p->ev_send);
+  if (p->ev_xchg) (void)hipEventDestroy(p->ev_xchg);
   if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
   delete p;
   return FEMASM_OK;
@@ -1038,6 +1094,26 @@ int femasm_plan_set_stream(femasm_plan *p, void *stream) {
   HIPCHK(hipStreamSynchronize(p->stream));
   p->stream = (hipStream_t)stream;
   p->own_stream = false;
+  return FEMASM_OK;
+}
+
+int femasm_plan_set_option(femasm_plan *p, const char *name, int64_t value) {
+  if (!p || !name) return fail(FEMASM_ERR_ARG, "null argument");
+  if (value < 0) return fail(FEMASM_ERR_ARG, "option %s: value %lld is negative (0 = automatic)", name, (long long)value);
+  const std::string n(name);
+  auto &o = p->opt;
+  if (n == "zc") o.zc = value;
+  else if (n == "s3_units") o.s3_units = value;
+  else if (n == "e2_yc") o.e2_yc = value;
+  else if (n == "rhs_grid") o.rhs_grid = value;
+  else if (n == "enr_scratch_mb") o.enr_scratch_mb = value;
+  else if (n == "s3_rowsweep") o.s3_rowsweep = value != 0;
+  else if (n == "p3_sweep") o.p3_sweep = value != 0;
+  else if (n == "e2_brick") o.e2_brick = value != 0;
+  else if (n == "e2_two_pass") o.e2_two_pass = value != 0;
+  else if (n == "enr_rhs_simple") o.enr_rhs_simple = value != 0;
+  else if (n == "debug") o.debug = value != 0;
+  else return fail(FEMASM_ERR_ARG, "unknown option '%s'", name);
   return FEMASM_OK;
 }
 
@@ -1610,12 +1686,20 @@ int femasm_error_integrals_static(femasm_plan *p, const double *u, double *sums)
   if (nb > STATIC_NB_MAX)
     return fail(FEMASM_ERR_ARG, "femasm_error_integrals_static: %lld elements exceed the static scratch (at most %lld per slab); "
                 "use femasm_error_integrals", (long long)p->nel, (long long)(256 * STATIC_NB_MAX));
-  double *partial = p->static_scratch;  // the looked-up device address, never the array's name
-  if (!partial) return fail(FEMASM_ERR_HIP, "static scratch of device %d was not set up", p->device);
   if (p->nel <= 0) {
     HIPCHK(hipMemsetAsync(sums, 0, 2 * sizeof(double), p->stream));
     return FEMASM_OK;
   }
+  if (!p->static_scratch) {  // no slice was free when the plan was created: plans may have been destroyed since
+    double *base = nullptr;
+    if (int rcs = static_scratch_for(p->device, &base)) return rcs;
+    p->static_slot = scratch_reserve(p->device, nb, &p->static_nslots);
+    if (p->static_slot >= 0) p->static_scratch = base + 2 * SCR_SLOT_NB * p->static_slot;
+  }
+  double *partial = p->static_scratch;  // (a slice of) the looked-up device address, never the array's name
+  if (!partial)
+    return fail(FEMASM_ERR_ARG, "femasm_error_integrals_static: no slice of the static scratch of device %d was left for this plan "
+                "(%lld workgroups; the plans alive on this GPU hold the rest): use femasm_error_integrals", p->device, (long long)nb);
   const Slab &s = p->s;
   if (p->kind == KIND_POISSON)
     hipLaunchKernelGGL(k_error_integrals<KIND_POISSON>, dim3((unsigned)nb), dim3(256), 0, p->stream, s, p->coords, u,
@@ -1665,15 +1749,28 @@ int femasm_interface_exchange(femasm_plan *p, void *comm, int rank_below, int ra
   const RcclApi &api = rccl_api();
   if (!api.ok) return fail(FEMASM_ERR_HIP, "RCCL (librccl.so: ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd) was not found");
   HIPCHK(hipSetDevice(p->device));
+  // The pair goes to the plan's communication stream, behind an event that marks "the send buffer is final" on the
+  // plan's stream (femasm_assemble_interface has just queued the kernels that fill it): the bulk of the assembly, queued
+  // on the plan's stream after this call, runs while the transfer waits for the neighbours and moves its 21 MB.
+  // femasm_interface_apply waits for the second event.
+  if (!p->comm_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&p->comm_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&p->ev_send, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&p->ev_xchg, hipEventDisableTiming));
+  }
+  HIPCHK(hipEventRecord(p->ev_send, p->stream));
+  HIPCHK(hipStreamWaitEvent(p->comm_stream, p->ev_send, 0));
   ncclComm_t c = (ncclComm_t)comm;
   ncclResult_t r = api.group_start();
   // one message per interface (S3:710-711 + 794-795: the stash of MatAssemblyEnd and DMLocalToGlobal's ghost sums):
   // the packed K rows and the b slice of node layer ks-1 to the rank below, the same of layer ke-1 from the rank above
-  if (r == ncclSuccess && do_send) r = api.send(p->send, (size_t)p->send_count, ncclDouble, rank_below, c, p->stream);
-  if (r == ncclSuccess && do_recv) r = api.recv(p->recv, (size_t)p->recv_count, ncclDouble, rank_above, c, p->stream);
+  if (r == ncclSuccess && do_send) r = api.send(p->send, (size_t)p->send_count, ncclDouble, rank_below, c, p->comm_stream);
+  if (r == ncclSuccess && do_recv) r = api.recv(p->recv, (size_t)p->recv_count, ncclDouble, rank_above, c, p->comm_stream);
   const ncclResult_t r2 = api.group_end();
   if (r == ncclSuccess) r = r2;
   if (r != ncclSuccess) return fail(FEMASM_ERR_HIP, "femasm_interface_exchange: RCCL: %s", api.err ? api.err(r) : "error");
+  HIPCHK(hipEventRecord(p->ev_xchg, p->comm_stream));
+  p->xchg_pending = true;
   return FEMASM_OK;
 }
 
@@ -1685,6 +1782,10 @@ int femasm_interface_apply(femasm_plan *p, const femasm_bc *bcs, double *csr_val
     return fail(FEMASM_ERR_ARG, "femasm_interface_apply needs device-resident csr_values / b");
   const int bc = bcs ? bcs->kind : FEMASM_BC_NONE;
   const int64_t plane = (p->s.nsd == 3) ? p->s.dim[0] * p->s.dim[1] : p->s.dim[0];
+  if (p->xchg_pending) {  // femasm_interface_exchange ran on the communication stream: its receive has to be complete
+    HIPCHK(hipStreamWaitEvent(p->stream, p->ev_xchg, 0));
+    p->xchg_pending = false;
+  }
   hipLaunchKernelGGL(k_iface_apply, dim3(nblk(plane, 4)), dim3(256), 0, p->stream, p->s, bc, csr_values, b,
                      p->recv, p->recv + p->recv_nnz);
   HIPCHK(hipGetLastError());

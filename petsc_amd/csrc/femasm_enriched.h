@@ -60,6 +60,7 @@ __device__ inline int64_t enr_flag(const double *rec, int base, int idx) {
 }
 // number of active families at local node a of the element whose record is rec
 __device__ inline int enr_active(const double *rec, int base, int a, int n_enr) {
+  if (n_enr <= 0) return 0;  // no families: the flags are not read (a 400-stride S3 record has none: double 400 is the next record)
   const int64_t t = enr_flag(rec, base, a), n = enr_flag(rec, base, 8 + a);
   if (t == 0 || n <= 0) return 0;
   return n < n_enr ? (int)n : n_enr;

@@ -26,12 +26,14 @@
 //   3  the geometry phase of the general kernels; in the row-sweep and RHS kernels: per-phase cycle counters
 //      (PH_* macros, dumped by femasm_plan_destroy)
 //   5  the b stores of the one-pass k_assemble_e2_rect<true>
-//   6  a 9-FMA stand-in for the 15-FMA isotropic block of add_block (numbers are wrong: timing only)
 //   7  the record stores of k_rhs_elem_elastic_runs;  8  also its arithmetic (input stream + LDS commit only)
 // femasm_enriched.h: 1 removes the ring stores of k_enr_elem (the VALU-versus-MFMA contraction-only timing);
 //   k_enr_node: 11 no global stores, 12 no staging/rounds, 13 no contraction, 14 all three (phase 1 + block zero/read)
 #ifndef FEMASM_EXP
 #define FEMASM_EXP 0
+#endif
+#if (FEMASM_EXP != 0 || defined(HX_EXP)) && !defined(FEMASM_DEV)
+#error "profiling branches (-DFEMASM_EXP=n, -DHX_EXP=n) are compiled only into development builds: add -DFEMASM_DEV"
 #endif
 
 namespace femasm {
@@ -236,13 +238,6 @@ __device__ inline void add_block(double *acc, const double *l, const double *m, 
     // B^T D B with isotropic D (E2:285-320, S3:470-515), zeros of B and D skipped:
     //   K[i][j] += D12 ga_i gb_j + D44 ga_j gb_i            (i != j)
     //   K[i][i] += D11 ga_i gb_i + D44 sum_{k!=i} ga_k gb_k
-#if FEMASM_EXP == 6  // profiling build: 9 FMAs per block instead of 15, wrong numbers, timing only
-#pragma unroll
-    for (int i = 0; i < D; i++)
-#pragma unroll
-      for (int j = 0; j < D; j++) acc[i * D + j] = fma(l[i], gb[j], acc[i * D + j]);
-    return;
-#endif
 #pragma unroll
     for (int i = 0; i < D; i++)
 #pragma unroll

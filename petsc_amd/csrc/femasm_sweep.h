@@ -1351,10 +1351,6 @@ __device__ inline void unit_half(const double *pd, const double *pe, const doubl
     for (int cc = 0; cc < 3; cc++) d[cc] = add ? d[cc] + acc[t * 3 + cc] : acc[t * 3 + cc];
   };
   double *d = stg + C * 81 + (MZ ? pz : 0);
-#if FEMASM_EXP == 21  // experiment: every deposit conflict-free (lane-consecutive addresses; wrong values), no stores
-  d = stg + C * 81 + MZ * 36;
-  py = 0, px = 0;
-#endif
   (void)e;
 #pragma unroll
   for (int pass = (MZ ? 0 : 1); pass < (MZ ? 1 : 3); pass++) {  // 0: far third, 1: middle third from below, 2: from above
@@ -1432,11 +1428,7 @@ __global__ __launch_bounds__(64, SU_OCC) void k_assemble_s3_unit(const Slab s, c
   const double s01 = sx * sy, s02 = sx * sz, s12 = sy * sz;
   // far-side neighbour steps in the node block: (dz, dy, dx) -> ((dz+1)*9 + (dy+1)*3 + (dx+1)) * 3 + column dof
   const int pz = AS ? -27 : 27, py = oy ? -9 : 9, px = ox ? -3 : 3;
-#if FEMASM_EXP == 21
-  double *stg = sh_stage + lane;
-#else
   double *stg = sh_stage + lx * NB + 39;
-#endif
   const bool lower = AS == 1;
   auto unit = [&](int u, UnitIn &in) -> bool {
     const int64_t i0 = ifirst + (int64_t)u * SU_TX;
@@ -1522,7 +1514,7 @@ __global__ __launch_bounds__(64, SU_OCC) void k_assemble_s3_unit(const Slab s, c
           const int it = h * NH + q;
           const bool always = FULL && it > 0 && 2 * 63 + 128 * it + 2 <= RUN;
           if (always || (s0 + 128 * it >= 0 && s0 + 128 * it + 2 <= n)) {
-#if FEMASM_EXP == 1 || FEMASM_EXP == 21
+#if FEMASM_EXP == 1
             asm volatile("" ::"v"(v[q].x), "v"(v[q].y));
 #else
             store_pair(dstp + 128 * it, v[q]);

@@ -33,7 +33,7 @@ EXPORTS = [
     "femasm_interface_set_buffers", "femasm_interface_apply", "femasm_compress_bc_rows", "femasm_plan_sync", "femasm_last_error",
     "femasm_version", "femasm_plan_set_fast_path", "femasm_plan_get_fast_path", "femasm_assemble_interface", "femasm_error_integrals", "femasm_fill_properties", "femasm_apply_operator",
     "femasm_coo_indices", "femasm_coord_moments", "femasm_rigid_body_modes", "femasm_zero_rows",
-    "femasm_error_integrals_static", "femasm_plan_set_enriched_contraction", "femasm_interface_exchange", "femasm_plan_set_async", "femasm_eliminate_columns",
+    "femasm_error_integrals_static", "femasm_plan_set_enriched_contraction", "femasm_interface_exchange", "femasm_plan_set_async", "femasm_eliminate_columns", "femasm_plan_set_option",
 ]
 
 
@@ -121,7 +121,8 @@ def _check(rc):
 class Plan:
     """One slab of the structured (DMDA) mesh on one GPU."""
 
-    def __init__(self, problem, M, N, P=1, coords=None, ks=0, ke=None, cks=None, cke=None, device=0, n_enr=0):
+    def __init__(self, problem, M, N, P=1, coords=None, ks=0, ke=None, cks=None, cke=None, device=0, n_enr=0,
+                 options=None):
         lib = load()
         nsd, dof, nen, ngp = _TRAITS[problem]
         if problem == ELASTIC3D_ENRICHED:
@@ -149,6 +150,8 @@ class Plan:
         self.els = max(ks - 1, 0)
         self.ele = ke - 1
         self.nel = plane_e * max(self.ele - self.els, 0)
+        for name, value in (options or {}).items():
+            self.set_option(name, value)
 
     def close(self):
         if getattr(self, "_h", None) and _lib is not None:  # _lib is gone at interpreter shutdown
@@ -156,6 +159,10 @@ class Plan:
             self._h = None
 
     __del__ = close
+
+    def set_option(self, name, value):
+        """Kernel variants / tile parameters for A/B runs and tests (include/femasm.h: femasm_plan_set_option)."""
+        _check(load().femasm_plan_set_option(self._h, C.c_char_p(name.encode()), C.c_int64(int(value))))
 
     def set_stream(self, stream_handle):
         _check(load().femasm_plan_set_stream(self._h, C.c_void_p(stream_handle)))

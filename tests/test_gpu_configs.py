@@ -91,15 +91,13 @@ def test_config1_poisson3d_32_whole_system(env):
 @pytest.mark.parametrize("kkernel", ["unit", "rowsweep"])
 def test_config4_elastic3d_128_uniform_level2_is_what_bench_times(env, monkeypatch, kkernel):
     """The benchmarked kernels at the benchmarked size: k_assemble_s3_unit with a whole x line per wave (chosen only at
-    such sizes) -- or, FEMASM_S3_ROWSWEEP=1, k_assemble_rowsweep<ELASTIC> with 64 node layers per workgroup --,
+    such sizes) -- or, with option "s3_rowsweep", k_assemble_rowsweep<ELASTIC> with 64 node layers per workgroup --,
     k_rhs_elem_elastic_runs<true>, k_bc_rows, on DMDASetUniformCoordinates."""
     torch, F, O, synth, dev = env["torch"], env["F"], env["O"], env["synth"], env["dev"]
-    if kkernel == "rowsweep":
-        monkeypatch.setenv("FEMASM_S3_ROWSWEEP", "1")
     nel = 128
     M = nel + 1
     coords = synth.uniform_coords(3, M, M, M, device=dev)
-    plan = F.Plan(F.ELASTIC3D_Q1, M, M, M, coords=coords)
+    plan = F.Plan(F.ELASTIC3D_Q1, M, M, M, coords=coords, options={"s3_rowsweep": 1} if kkernel == "rowsweep" else None)
     props = torch.empty(plan.nel * 400, dtype=torch.float64, device=dev)
     plan.fill_properties(props, 90.0, 0.28, 400)   # as bench.py does
     vals = torch.full((plan.nnz,), float("nan"), dtype=torch.float64, device=dev)

@@ -60,10 +60,11 @@ def make_case(env, dims, n_enr, perturb=True, sgfem=1, base=408, partial=False, 
                 sgfem=sgfem, dirichlet=dirichlet, D=D)
 
 
-def gpu_assemble(env, case, mode=-1, ks=0, ke=None):
+def gpu_assemble(env, case, mode=-1, ks=0, ke=None, options=None):
     torch, F, dev = env["torch"], env["F"], env["dev"]
     M, N, P = case["dims"]
-    plan = F.Plan(F.ELASTIC3D_ENRICHED, M, N, P, coords=torch.from_numpy(case["coords"]).to(dev), n_enr=case["n_enr"])
+    plan = F.Plan(F.ELASTIC3D_ENRICHED, M, N, P, coords=torch.from_numpy(case["coords"]).to(dev), n_enr=case["n_enr"],
+                  options=options)
     if mode >= 0:
         plan.set_enriched_contraction(mode)
     assert plan.dof == case["D"] or True
@@ -238,8 +239,7 @@ def test_small_scratch_ring_gives_the_same_matrix(env, monkeypatch):
     case = make_case(env, (6, 5, 8), 1)
     p0, v0, b0 = gpu_assemble(env, case, 1)
     p0.close()
-    monkeypatch.setenv("FEMASM_ENR_SCRATCH_MB", "1")
-    p1, v1, b1 = gpu_assemble(env, case, 1)
+    p1, v1, b1 = gpu_assemble(env, case, 1, options={"enr_scratch_mb": 1})
     p1.close()
     assert np.array_equal(v0, v1) and np.array_equal(b0, b1)
     assert rel(v1, case["K"]) <= TOL

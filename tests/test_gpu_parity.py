@@ -74,11 +74,11 @@ def make_case(env, kind, dims, perturb=True, vary_material=False):
                 bc=F.BC_S3_ALLFACES_EXACT, rp=rp, ci=ci, K=K, b=b)
 
 
-def gpu_assemble(env, case, host_buffers=False, bc=None):
+def gpu_assemble(env, case, host_buffers=False, bc=None, options=None):
     torch, F, dev = env["torch"], env["F"], env["dev"]
     M, N, P = case["dims"]
     to = (lambda a: a) if host_buffers else (lambda a: torch.from_numpy(a).to(dev))
-    plan = F.Plan(case["problem"], M, N, P, coords=to(case["coords"]))
+    plan = F.Plan(case["problem"], M, N, P, coords=to(case["coords"]), options=options)
     if host_buffers:
         vals, b = np.full(plan.nnz, np.nan), np.full(plan.nrows, np.nan)
     else:
@@ -471,7 +471,7 @@ def test_results_are_bitwise_reproducible(env):
 @pytest.mark.parametrize("perturb", [False, True])
 def test_s3_rhs_persistent_waves_walk_several_tasks(env, monkeypatch, perturb):
     """k_rhs_elem_elastic_runs is launched as one resident set of waves that stride over the (chunk, row, run) tasks;
-    small meshes give every wave one task, so the grid is capped here (FEMASM_RHS_GRID) to make each wave walk many,
+    small meshes give every wave one task, so the grid is capped here (option "rhs_grid") to make each wave walk many,
     on the box path and on the general one"""
     torch, F, dev, O = env["torch"], env["F"], env["dev"], env["O"]
     M, N, P = 35, 9, 40          # 3 runs x 8 rows x 2 chunks = 48 tasks
@@ -482,8 +482,7 @@ def test_s3_rhs_persistent_waves_walk_several_tasks(env, monkeypatch, perturb):
     rp, ci = O.pattern(3, 3, M, N, P)
     K, b = O.assemble_elastic3d(M, N, P, coords, props, rp, ci)
     O.bc_s3(M, N, P, coords, rp, ci, K, b)
-    monkeypatch.setenv("FEMASM_RHS_GRID", "5")
-    plan = F.Plan(F.ELASTIC3D_Q1, M, N, P, coords=torch.from_numpy(coords).to(dev))
+    plan = F.Plan(F.ELASTIC3D_Q1, M, N, P, coords=torch.from_numpy(coords).to(dev), options={"rhs_grid": 5})
     gb = torch.full((plan.nrows,), float("nan"), dtype=torch.float64, device=dev)
     plan.assemble_system(None, gb, material=torch.from_numpy(props).to(dev), stride=400, bc=F.BC_S3_ALLFACES_EXACT)
     plan.close()
@@ -494,8 +493,8 @@ def test_s3_rhs_persistent_waves_walk_several_tasks(env, monkeypatch, perturb):
 @pytest.mark.parametrize("dims", [(45, 23, 36), (38, 5, 7), (10, 4, 4)])
 def test_s3_box_kernels_unit_and_rowsweep(env, monkeypatch, variant, dims):
     """Elastic K on a rectilinear mesh (level 2) has two kernels: k_assemble_s3_unit (default; a wave walks
-    FEMASM_S3_UNITS x-consecutive 8-node units, chosen from the mesh size otherwise, so small meshes only ever see 1)
-    and the persistent k_assemble_rowsweep (FEMASM_S3_ROWSWEEP=1).  Both against the oracle, with a material that
+    "s3_units" x-consecutive 8-node units, chosen from the mesh size otherwise, so small meshes only ever see 1)
+    and the persistent k_assemble_rowsweep (option "s3_rowsweep").  Both against the oracle, with a material that
     differs from element to element, on meshes whose x range is not a multiple of the unit."""
     torch, F = env["torch"], env["F"]
     case = make_case(env, "s3", dims, perturb=False)
@@ -508,11 +507,8 @@ def test_s3_box_kernels_unit_and_rowsweep(env, monkeypatch, variant, dims):
     O = env["O"]
     K, b = O.assemble_elastic3d(M, N, P, case["coords"], case["props"], case["rp"], case["ci"])
     O.bc_s3(M, N, P, case["coords"], case["rp"], case["ci"], K, b)
-    if variant == "rowsweep":
-        monkeypatch.setenv("FEMASM_S3_ROWSWEEP", "1")
-    else:
-        monkeypatch.setenv("FEMASM_S3_UNITS", variant.split("=")[1])
-    plan, vals, gb = gpu_assemble(env, case)
+    opts = {"s3_rowsweep": 1} if variant == "rowsweep" else {"s3_units": int(variant.split("=")[1])}
+    plan, vals, gb = gpu_assemble(env, case, options=opts)
     assert plan.fast_path() == 2
     assert not np.isnan(vals).any()
     assert rel(vals, K) <= TOL and rel(gb, b) <= TOL
@@ -530,7 +526,7 @@ def test_element_soa_material_gives_the_same_k_as_the_records(env, monkeypatch, 
     if variant == "rowsweep":
         if kind != "s3" or mesh != "uniform":
             pytest.skip("the row-sweep variant only differs for S3 boxes")
-        monkeypatch.setenv("FEMASM_S3_ROWSWEEP", "1")
+    opts = {"s3_rowsweep": 1} if variant == "rowsweep" else None
     case = make_case(env, kind, dims, perturb=(mesh == "perturbed"))
     rng = np.random.default_rng(11)
     st = case["stride"]
@@ -544,7 +540,7 @@ def test_element_soa_material_gives_the_same_k_as_the_records(env, monkeypatch, 
     pad = 5                                            # plane distance larger than the element count
     planes = torch.from_numpy(np.concatenate([Ee, np.zeros(pad), nue])).to(dev)
     coords = torch.from_numpy(case["coords"]).to(dev)
-    plan = F.Plan(case["problem"], *case["dims"], coords=coords)
+    plan = F.Plan(case["problem"], *case["dims"], coords=coords, options=opts)
     v_aos = torch.full((plan.nnz,), float("nan"), dtype=torch.float64, device=dev)
     v_soa = torch.full((plan.nnz,), float("nan"), dtype=torch.float64, device=dev)
     b_soa = torch.full((plan.nrows,), float("nan"), dtype=torch.float64, device=dev)
@@ -576,12 +572,10 @@ def test_element_soa_material_gives_the_same_k_as_the_records(env, monkeypatch, 
 def test_e2_general_kernels_element_matrix_and_brick(env, monkeypatch, kernel, dims):
     """Plane strain on general quadrilaterals has two kernels for the interior nodes: k_assemble_ke_e2 (default: the
     ten unique 2 x 2 blocks of each element matrix formed once, node rows gathered from LDS; 15 x 7 node tiles) and the
-    brick kernel k_assemble_rows (FEMASM_E2_BRICK=1).  Both against the oracle, per-Gauss-point material, on perturbed
+    brick kernel k_assemble_rows (option "e2_brick").  Both against the oracle, per-Gauss-point material, on perturbed
     meshes whose extents are not multiples of the tile."""
     case = make_case(env, "e2", dims, perturb=True, vary_material=True)
-    if kernel == "brick":
-        monkeypatch.setenv("FEMASM_E2_BRICK", "1")
-    plan, vals, gb = gpu_assemble(env, case)
+    plan, vals, gb = gpu_assemble(env, case, options={"e2_brick": 1} if kernel == "brick" else None)
     assert plan.fast_path() == 0
     assert not np.isnan(vals).any()
     assert rel(vals, case["K"]) <= TOL and rel(gb, case["b"]) <= TOL
@@ -640,11 +634,9 @@ def test_element_soa_material_on_an_upper_slab(env, mesh):
 def test_p3_general_kernels_element_matrix_and_node_row(env, monkeypatch, kernel, dims):
     """Poisson K on general hexahedra has two kernels: k_assemble_ke_p3 (default: the 36 unique entries of each element
     matrix formed once, node rows gathered from LDS; 15 x 3 node tiles) and the node-row kernel k_assemble_sweep_p3
-    (FEMASM_P3_SWEEP=1).  Both against the oracle on perturbed meshes whose extents are not multiples of either tile."""
+    (option "p3_sweep").  Both against the oracle on perturbed meshes whose extents are not multiples of either tile."""
     case = make_case(env, "p3", dims, perturb=True)
-    if kernel == "sweep":
-        monkeypatch.setenv("FEMASM_P3_SWEEP", "1")
-    plan, vals, gb = gpu_assemble(env, case)
+    plan, vals, gb = gpu_assemble(env, case, options={"p3_sweep": 1} if kernel == "sweep" else None)
     assert plan.fast_path() == 0
     assert not np.isnan(vals).any()
     assert rel(vals, case["K"]) <= TOL and rel(gb, case["b"]) <= TOL

@@ -31,6 +31,35 @@ def test_error_integrals_static_equals_error_integrals_twice_smaller_second():
             plan.close()
 
 
+def test_error_integrals_static_two_plans_on_two_streams_do_not_share_scratch():
+    """Two plans of one GPU (two slabs, say) driven on two streams at once: each plan owns a slice of the GPU's static
+    array, so their partial sums cannot meet (round-2 advice: one shared array raced)."""
+    import torch
+    from petsc_amd import femasm as F
+    from petsc_amd import synth
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    plans, us, wants, sums, streams = [], [], [], [], []
+    for (M, N, P) in ((70, 61, 52), (33, 90, 41)):
+        coords = synth.perturb_coords(synth.uniform_coords(3, M, N, P, device=dev), 3, M, N, P)
+        plan = F.Plan(F.ELASTIC3D_Q1, M, N, P, coords=coords)
+        u = torch.from_numpy(rng.uniform(-1.0, 1.0, size=M * N * P * 3)).to(dev)
+        wants.append(plan.error_integrals(u))
+        st = torch.cuda.Stream()
+        plan.set_stream(st.cuda_stream)
+        plans.append(plan); us.append(u); streams.append(st)
+        sums.append(torch.full((2,), float("nan"), dtype=torch.float64, device=dev))
+    torch.cuda.synchronize()
+    for rep in range(20):  # interleaved: the two kernels pairs overlap on the device
+        for q in range(2):
+            plans[q].error_integrals_static(us[q], sums[q])
+    torch.cuda.synchronize()
+    for q in range(2):
+        got = sums[q].cpu().numpy()
+        assert got[0] == wants[q][0] and got[1] == wants[q][1], (q, got, wants[q])
+        plans[q].close()
+
+
 def test_error_integrals_static_rejects_what_it_cannot_do():
     import torch
     from petsc_amd import femasm as F
