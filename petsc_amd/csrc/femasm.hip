@@ -430,7 +430,7 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
         // level 1 of the elastic kind: any hexahedra, the material taken out of the Gauss-point loop (femasm_hex.h).
         const int64_t tiles = ((b.x1 - b.x0 + HX_TX - 1) / HX_TX) * ((b.y1 - b.y0 + HX_TY - 1) / HX_TY);
         // node layers per workgroup: the chunking that wastes least -- a chunk of zc node layers sweeps zc + 1 element
-        // layers, and the last round of the 2 x CUs resident workgroups should be full
+        // layers, and the last round of the resident workgroups (one per CU) should be full
         const int64_t nz = z1 - z0, resident = (int64_t)p->ncu;  // one 12-wave workgroup per CU
         int64_t zc = nz;
         double best = -1.0;
@@ -1048,12 +1048,12 @@ int femasm_plan_destroy(femasm_plan *p) {
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
 #if HX_EXP == 9
-  {  // phase clocks of k_assemble_s3_hex (profiling build): one workgroup, waves 0 and 4, summed over launches
+  {  // phase clocks of k_assemble_s3_hex (profiling build): one workgroup, row waves 0 and 8, summed over launches
     unsigned long long t[32];
     if (p->bad && hipMemcpy(t, p->bad, sizeof t, hipMemcpyDeviceToHost) == hipSuccess && t[24]) {
       const char *nm[8] = {"record", "B1", "contract", "B2", "deposit", "B3", "store", "B4"};
       fprintf(stderr, "[femasm hex phases] most workgroups seen together on one CU: %llu; cycles per step (steps %llu):", t[25], t[24]);
-      for (int q = 0; q < 8; q++) fprintf(stderr, " %s w0 %.0f w4 %.0f |", nm[q], (double)t[8 + q] / t[24], (double)t[16 + q] / t[24]);
+      for (int q = 0; q < 8; q++) fprintf(stderr, " %s w0 %.0f w8 %.0f |", nm[q], (double)t[8 + q] / t[24], (double)t[16 + q] / t[24]);
       fprintf(stderr, "\n");
     }
   }

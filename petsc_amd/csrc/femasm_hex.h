@@ -31,6 +31,9 @@
 // a workgroup is a multiple of four waves here.
 #pragma once
 #include "femasm_sweep.h"
+#ifndef HX_UNROLL
+#define HX_UNROLL 2
+#endif
 #ifndef HX_EXP
 #define HX_EXP 0  // profiling builds: 1 no global stores, 2 no store phase, 3 no record arithmetic, 4 no contraction,
 #endif            // 9 phase clocks of waves 0 and 4 of one workgroup (printed by femasm_plan_destroy)
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(HX_NT, 3) void k_assemble_s3_hex(const Slab s, cons
 #pragma unroll
       for (int b = 0; b < 4; b++) ob[b] = nb[b] * CS, obz[b] = (8 + (nb[b] >> 1)) * CS + 8 * (nb[b] & 1);
 #if HX_EXP != 4
-#pragma unroll 1
+#pragma unroll HX_UNROLL
       for (int p = 0; p < 8; p++) {
         const char *rp = base + p * (HX_CELLS * CS);
         // all eleven reads of this Gauss point first, one wait, then the 39 products
