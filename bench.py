@@ -245,7 +245,7 @@ GENERAL_FLOPS_PER_ELEMENT = {
     "elastic3d": 8 * (2 * 72 + 60 + 2 * 72 + 20 + 64 * 2 * 21 + 8 * 9),
 }
 
-# k_assemble_s3_hex (level 1): per Gauss point the same geometry (2*72 + 60 + 2*72 + the 96 products of the reference
+# k_assemble_s3_hex2 (level 1): per Gauss point the same geometry (2*72 + 60 + 2*72 + the 96 products of the reference
 # gradients' factors), 64 node pairs x 9 FMAs on w detJ-scaled gradients (+ 24 products), and once per element 64 x 21.
 HEX_FLOPS_PER_ELEMENT = 8 * (2 * 72 + 60 + 2 * 72 + 96 + 64 * 2 * 9 + 24) + 64 * 21
 
@@ -259,7 +259,7 @@ def kernel_name(wl, level, args):
         return "k_assemble_e2_rect" if level == 2 else "k_assemble_ke_e2"
     if wl == "poisson3d":
         return {2: "k_assemble_p3_rect", 1: "k_assemble_rowsweep<POISSON3D>"}.get(level, "k_assemble_ke_p3")
-    return {2: "k_assemble_s3_unit", 1: "k_assemble_s3_hex"}.get(level, "k_assemble_sweep<ELASTIC3D>")
+    return {2: "k_assemble_s3_unit", 1: "k_assemble_s3_hex2"}.get(level, "k_assemble_sweep<ELASTIC3D>")
 
 
 def measure_peak(torch, nbytes, dev):
@@ -466,7 +466,7 @@ def main():
             roof["fp64_peak_tflops"] = 78.6
             roof["fp64_flops_per_element"] = GENERAL_FLOPS_PER_ELEMENT[wl]
             if level == 1:
-                # k_assemble_s3_hex takes the material out of the Gauss-point loop: what it executes per element
+                # k_assemble_s3_hex2 takes the material out of the Gauss-point loop: what it executes per element
                 roof["fp64_flops_executed_per_element"] = HEX_FLOPS_PER_ELEMENT
                 roof["fp64_tflops_executed"] = HEX_FLOPS_PER_ELEMENT * float(st.nel) / (facts["main_ms"] * 1e-3) / 1e12
         return roof

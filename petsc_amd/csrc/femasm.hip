@@ -7,7 +7,7 @@
 #include "../../include/femasm.h"
 #include "femasm_kernels.h"
 #include "femasm_sweep.h"
-#include "femasm_hex.h"
+#include "femasm_hex2.h"
 #include "femasm_enriched.h"
 
 #include <hipcub/hipcub.hpp>
@@ -416,6 +416,15 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
       const bool fast = p->fast_level >= 1;  // 2: verified boxes; 1: P3 parallelepipeds, S3 any hexahedra with one (E, nu) each
       const bool timed = p->time_main && !iface;
       const bool rect = fast && p->fast_level == 2;  // level 2: geometry from three coordinate lines (launch_rect_check ran)
+      if (fast && KIND == KIND_ELASTIC && !rect) {
+        // level 1 of the elastic kind, pre-pass: premise test (one (E, nu) per element) + the elements' coefficients into
+        // the element-vector scratch, which is free until the RHS pass (k_s3_elem_coefs in femasm_hex2.h)
+        const int64_t nel_here = (M - 1) * (N - 1) * (p->s.ele - p->s.els);
+        if (4 * nel_here > p->elemF_count) return fail(FEMASM_ERR_ARG, "element scratch too small for the coefficient pre-pass");
+        const int64_t nb = (nel_here + 127) / 128;
+        hipLaunchKernelGGL(k_s3_elem_coefs, dim3((unsigned)(nb < 65536 ? nb : 65536)), dim3(256), 0, p->stream, p->s, a, p->elemF);
+        HIPCHK(hipGetLastError());
+      }
       if (timed) {
         HIPCHK(hipEventRecord(p->ev[4], p->stream));
         const bool aos3 = (KIND != KIND_POISSON) && mat && mat->layout == FEMASM_MAT_AOS;
@@ -427,40 +436,31 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
                         (aos3 ? 16.0 * T::NGP * (double)(M - 1) * (N - 1) * (z1 - z0 + 1) : 0.0);
       }
       if (fast && KIND == KIND_ELASTIC && !rect) {
-        // level 1 of the elastic kind: any hexahedra, the material taken out of the Gauss-point loop (femasm_hex.h).
-        const int64_t tiles = ((b.x1 - b.x0 + HX_TX - 1) / HX_TX) * ((b.y1 - b.y0 + HX_TY - 1) / HX_TY);
+        // level 1 of the elastic kind: any hexahedra, the material taken out of the Gauss-point loop
+        // (femasm_hex2.h: four-wave workgroups on 8 x 2 node tiles, two per CU)
+        const int64_t tiles = ((b.x1 - b.x0 + H2_TX - 1) / H2_TX) * ((b.y1 - b.y0 + H2_TY - 1) / H2_TY);
         // node layers per workgroup: the chunking that wastes least -- a chunk of zc node layers sweeps zc + 1 element
-        // layers, and the last round of the resident workgroups (one per CU) should be full
-        const int64_t nz = z1 - z0, resident = (int64_t)p->ncu;  // one 12-wave workgroup per CU
+        // layers, and the last round of the resident workgroups should be full
+        const int64_t nz = z1 - z0, resident = (int64_t)p->ncu * 2;
         int64_t zc = nz;
         double best = -1.0;
         for (int64_t chunks = 1; chunks <= nz; chunks++) {
           const int64_t c = (nz + chunks - 1) / chunks, rc = (nz + c - 1) / c;
           if (c < 6 && chunks > 1) break;
           const int64_t W = tiles * rc, rounds = (W + resident - 1) / resident;
-          const double eff = (double)W / (double)(rounds * resident) * (double)nz / (double)(nz + rc);
+          // (workgroups differ in speed by 10-15 %: the fewer rounds, the more of the last one is spent waiting for the
+          // slowest -- 128^3: one chunk = two rounds 1.81 ms, three chunks 1.745 ms, five 1.78 ms)
+          const double eff = (double)W / (double)(rounds * resident) * (double)nz / (double)(nz + rc) * (1.0 - 0.25 / (double)rounds);
           if (eff > best + 1e-9) { best = eff; zc = c; }
         }
         if (p->opt.zc > 0) zc = p->opt.zc;
         KArgs az = a;
         az.zc = (int32_t)zc;
-        dim3 grid((unsigned)((b.x1 - b.x0 + HX_TX - 1) / HX_TX), (unsigned)((b.y1 - b.y0 + HX_TY - 1) / HX_TY),
+        az.ecoef = p->elemF;
+        dim3 grid((unsigned)((b.x1 - b.x0 + H2_TX - 1) / H2_TX), (unsigned)((b.y1 - b.y0 + H2_TY - 1) / H2_TY),
                   (unsigned)((z1 - z0 + zc - 1) / zc));
-#if HX_EXP == 9
-        {
-          static bool once = false;
-          if (!once) {
-            once = true;
-            int nb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_assemble_s3_hex, HX_NT, 0);
-            hipFuncAttributes fa;
-            (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_assemble_s3_hex));
-            fprintf(stderr, "[femasm hex] occupancy API: %d workgroups per CU; static LDS %zu B, regs %d; grid %u x %u x %u, zc %lld\n", nb,
-                    fa.sharedSizeBytes, fa.numRegs, grid.x, grid.y, grid.z, (long long)zc);
-          }
-        }
-#endif
-        hipLaunchKernelGGL(k_assemble_s3_hex, grid, dim3(HX_NT), 0, p->stream, p->s, az);
+        if (p->opt.debug) fprintf(stderr, "[femasm] elastic level 1: grid %u x %u x %u, %lld node layers per workgroup\n", grid.x, grid.y, grid.z, (long long)zc);
+        hipLaunchKernelGGL(k_assemble_s3_hex2, grid, dim3(H2_NT), 0, p->stream, p->s, az);
         p->used_fast = true;
       } else if (fast) {
         constexpr int TX = RowSweep<KIND>::TX, TY = RowSweep<KIND>::TY;
@@ -1047,14 +1047,15 @@ int femasm_plan_destroy(femasm_plan *p) {
   if (!p) return FEMASM_OK;
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
-#if HX_EXP == 9
-  {  // phase clocks of k_assemble_s3_hex (profiling build): one workgroup, row waves 0 and 8, summed over launches
+#if H2_EXP == 9
+  {  // phase clocks of k_assemble_s3_hex2 (profiling build): one workgroup, two of its waves, summed over launches
     unsigned long long t[32];
     if (p->bad && hipMemcpy(t, p->bad, sizeof t, hipMemcpyDeviceToHost) == hipSuccess && t[24]) {
       const char *nm[8] = {"record", "B1", "contract", "B2", "deposit", "B3", "store", "B4"};
       fprintf(stderr, "[femasm hex phases] most workgroups seen together on one CU: %llu; cycles per step (steps %llu):", t[25], t[24]);
       for (int q = 0; q < 8; q++) fprintf(stderr, " %s w0 %.0f w8 %.0f |", nm[q], (double)t[8 + q] / t[24], (double)t[16 + q] / t[24]);
       fprintf(stderr, "\n");
+      if (t[27]) fprintf(stderr, "[femasm hex phases] workgroups %llu, mean life %.1f us = %.0f cycles (%.2f GHz)\n", t[27], (double)t[26] / t[27] / 100.0, (double)t[28] / t[27], (double)t[28] / t[26] / 10.0);
     }
   }
 #endif

@@ -141,6 +141,7 @@ struct KArgs {
   int32_t rect;           // row-sweep kernels: the mesh was verified rectilinear (k_check_rectilinear): geometry from 1-D lines
   int32_t ends;           // the interior kernel writes the Dirichlet rows of the x-end nodes of its lines; k_bc_rows skips them
   double *bout;           // k_assemble_e2_rect: also write b of its node rows (E2 one-pass form), or null
+  const double *ecoef;    // k_assemble_s3_hex2: (c11, c12, c44, -) per element of layers [els, ele) (k_s3_elem_coefs)
   int32_t cond;           // general kernels: run only if bad[1] != 0, i.e. the fast kernel launched before on the same rows
                           // found its premise broken (femasm_assemble_interface: no host round trip)
 };

@@ -747,8 +747,8 @@ def test_sheared_mesh_elastic_falls_back_poisson_stays_fast(env):
 @pytest.mark.parametrize("dims", [(8, 7, 9), (14, 11, 6), (27, 10, 47), (9, 30, 5), (3, 3, 3), (45, 23, 36)])
 @pytest.mark.parametrize("material", ["uniform_records", "per_element", "uniform_args"])
 def test_s3_hexahedron_kernel_level_1(env, dims, material):
-    """k_assemble_s3_hex (femasm_hex.h): any hexahedra, one (E, nu) per element taken out of the Gauss-point loop.
-    Perturbed meshes whose extents are not multiples of its 6 x 4 node tile nor of its z chunks, material the same in
+    """k_assemble_s3_hex2 (femasm_hex2.h): any hexahedra, one (E, nu) per element taken out of the Gauss-point loop.
+    Perturbed meshes whose extents are not multiples of its 8 x 2 node tile nor of its z chunks, material the same in
     every record / different per element / passed as two numbers; the plan must stay at level 1 and K, b match the
     oracle's per-Gauss-point loops (S3:450-518)."""
     torch, F, dev, O = env["torch"], env["F"], env["dev"], env["O"]
