@@ -1378,8 +1378,7 @@ __global__ __launch_bounds__(64, SU_OCC) void k_assemble_s3_unit(const Slab s, c
   using R_ = RowSweep<KIND_ELASTIC>;
   constexpr int NB = R_::NB, RUN = SU_TX * NB;
   constexpr int PAD = 16;  // doubles either side of the run: the store loop reads whole 16-byte chunks from a line boundary
-  __shared__ __attribute__((aligned(16))) double sh_all[PAD + RUN + PAD];
-  double *sh_stage = sh_all + PAD;
+  __shared__ __attribute__((aligned(16))) double sh_all[PAD + RUN + PAD + 2];
   const int lane = threadIdx.x;
   PH_DECL;
   const int e = lane & 3, lx = (lane >> 2) & 7, AS = lane >> 5;  // AS = 1: element layer kn-1 (the node on its top face)
@@ -1428,11 +1427,17 @@ __global__ __launch_bounds__(64, SU_OCC) void k_assemble_s3_unit(const Slab s, c
   const double s01 = sx * sy, s02 = sx * sz, s12 = sy * sz;
   // far-side neighbour steps in the node block: (dz, dy, dx) -> ((dz+1)*9 + (dy+1)*3 + (dx+1)) * 3 + column dof
   const int pz = AS ? -27 : 27, py = oy ? -9 : 9, px = ox ? -3 : 3;
-  double *stg = sh_stage + lx * NB + 39;
   const bool lower = AS == 1;
   auto unit = [&](int u, UnitIn &in) -> bool {
     const int64_t i0 = ifirst + (int64_t)u * SU_TX;
     if (i0 >= a.x1) return false;
+    // the run in the CSR array and in the stage: the stage copy starts (head & 1) doubles above a 16-byte boundary of LDS,
+    // head = the run's distance from a 128-byte line of HBM, so that a 16-byte chunk of HBM is a 16-byte chunk of LDS
+    // (one ds_read_b128 per chunk in the copy-out instead of a ds_read2_b64 at a quarter of its rate)
+    double *runp = a.out + (row_start(s, i0, j, kn, 0) - a.base_off);
+    const int head = (int)((reinterpret_cast<uintptr_t>(runp) & 127) >> 3);  // doubles above a line boundary
+    double *sh_stage = sh_all + PAD + (head & 1);
+    double *stg = sh_stage + lx * NB + 39;
     const double xa = in.xa, xb = in.xb;
     const double(&m)[16] = in.m;
     const int nvx = (a.x1 - i0 < SU_TX) ? (int)(a.x1 - i0) : SU_TX;
@@ -1479,8 +1484,6 @@ __global__ __launch_bounds__(64, SU_OCC) void k_assemble_s3_unit(const Slab s, c
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     PH_ACC(1, 2);
     const int n = nvx * NB;
-    double *runp = a.out + (row_start(s, i0, j, kn, 0) - a.base_off);
-    const int head = (int)((reinterpret_cast<uintptr_t>(runp) & 127) >> 3);  // doubles above a line boundary
     constexpr int NIT = (RUN / 2 + 8 + 63) / 64;
     // chunk q = the q-th 16 bytes from that boundary = stage[2q - head, 2q - head + 1]; whole chunks here, the two
     // possible half chunks (an odd head, an odd end) after the loop
@@ -1503,7 +1506,7 @@ __global__ __launch_bounds__(64, SU_OCC) void k_assemble_s3_unit(const Slab s, c
           const int it = h * NH + q;
           int o = 128 * it;
           if (128 * (it + 1) > RUN + PAD) o = (s0 + o + 2 <= RUN + PAD) ? o : 0;  // last round: stay inside the array
-          v[q] = make_double2(src[o], src[o + 1]);
+          v[q] = *reinterpret_cast<const double2 *>(src + o);  // 16-byte aligned: s0 + (head & 1) and o are even
         }
         if (h == NPART - 1) {
           PH_PIN(v[0].x + v[NH - 1].y);
