@@ -431,9 +431,13 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
         const double nint = (double)(M - 2) * (double)(N - 2) * (double)(z1 - z0);  // interior nodes = rows / dof
         // stores of the interior rows + one read of the coordinates and of E,nu at the Gauss points
         // (at level 2 the coordinates are read by the rectilinearity pre-pass, not by this kernel)
+        // (elastic level 1: the E, nu of the records are read by the pre-pass, outside this bracket; the kernel itself reads
+        // the 32 bytes per element the pre-pass left, whatever the material layout)
+        const bool hex2 = fast && KIND == KIND_ELASTIC && !rect;
         p->bytes_main = 8.0 * nint * 27.0 * T::DOF * T::DOF +
                         (p->fast_level == 2 ? 0.0 : 8.0 * T::NSD * (double)M * N * (z1 - z0 + 2)) +
-                        (aos3 ? 16.0 * T::NGP * (double)(M - 1) * (N - 1) * (z1 - z0 + 1) : 0.0);
+                        (hex2 ? 32.0 * (double)(M - 1) * (N - 1) * (z1 - z0 + 1)
+                              : (aos3 ? 16.0 * T::NGP * (double)(M - 1) * (N - 1) * (z1 - z0 + 1) : 0.0));
       }
       if (fast && KIND == KIND_ELASTIC && !rect) {
         // level 1 of the elastic kind: any hexahedra, the material taken out of the Gauss-point loop
