@@ -703,11 +703,11 @@ void launch_enr_elem(femasm_plan *p, const EnrArgs &a, int64_t nelem, bool mfma)
   hipLaunchKernelGGL((k_enr_elem<S, false>), grid, dim3(64 * NW), 0, p->stream, p->s, a);
 }
 
-template <int S>
+template <int S, bool BOX>
 void launch_enr_node(femasm_plan *p, const EnrArgs &a, int64_t nnodes) {
-  constexpr int per_wg = EnrNodeCfg<S>::NW * EnrNodeCfg<S>::NPW;
+  constexpr int per_wg = EnrNodeCfg<S, BOX>::NW * EnrNodeCfg<S, BOX>::NPW;
   const dim3 grid((unsigned)((nnodes + per_wg - 1) / per_wg));
-  hipLaunchKernelGGL((k_enr_node<S>), grid, dim3(64 * EnrNodeCfg<S>::NW), 0, p->stream, p->s, a);
+  hipLaunchKernelGGL((k_enr_node<S, BOX>), grid, dim3(64 * EnrNodeCfg<S, BOX>::NW), 0, p->stream, p->s, a);
 }
 
 int assemble_enriched(femasm_plan *p, const femasm_material *mat, int bc, double *csr_values, double *b,
@@ -788,6 +788,7 @@ int assemble_enriched(femasm_plan *p, const femasm_material *mat, int bc, double
     if (stats) HIPCHK(hipEventRecord(p->ev[4], p->stream));
     // default: one node-centric pass (k_enr_node), nothing but the CSR values leaves the chip; the two-kernel
     // form (element matrices through a scratch ring) is what femasm_plan_set_enriched_contraction(0 | 1) selects
+    bool box = false;
     auto node_pass = [&](double *out, int64_t l0, int64_t l1, int iface) {
       if (l1 <= l0) return;
       EnrArgs g = a;
@@ -797,20 +798,46 @@ int assemble_enriched(femasm_plan *p, const femasm_material *mat, int bc, double
       g.iface = iface;
       g.base_off = iface ? row_start(s, 0, 0, l0, 0) : 0;
       const int64_t nn = M * N * (l1 - l0);
-      switch (S) {
-        case 1: launch_enr_node<1>(p, g, nn); break;
-        case 2: launch_enr_node<2>(p, g, nn); break;
-        case 3: launch_enr_node<3>(p, g, nn); break;
-        default: launch_enr_node<4>(p, g, nn); break;
+      if (box) {
+        switch (S) {
+          case 1: launch_enr_node<1, true>(p, g, nn); break;
+          case 2: launch_enr_node<2, true>(p, g, nn); break;
+          case 3: launch_enr_node<3, true>(p, g, nn); break;
+          default: launch_enr_node<4, true>(p, g, nn); break;
+        }
+      } else {
+        switch (S) {
+          case 1: launch_enr_node<1, false>(p, g, nn); break;
+          case 2: launch_enr_node<2, false>(p, g, nn); break;
+          case 3: launch_enr_node<3, false>(p, g, nn); break;
+          default: launch_enr_node<4, false>(p, g, nn); break;
+        }
       }
     };
     if (!two_phase) {
-      if (s.ks > 0 && p->send) {
-        node_pass(p->sfull, s.ks - 1, s.ks, 1);
-        if (int rcp = launch_iface_pack(p)) return rcp;
+      // level 2 of this kind (round 3): box elements with one material each, both premises tested on the device (the
+      // rectilinearity pre-pass and phase 1 of the kernel raise bad[1]); on a failure K is assembled again by the
+      // general form below and the plan stays there
+      for (int attempt = 0; attempt < 2; attempt++) {
+        box = p->fast_level == 2;
+        if (box) {
+          if (int rcr = launch_rect_check(p)) return rcr;
+        }
+        if (s.ks > 0 && p->send) {
+          node_pass(p->sfull, s.ks - 1, s.ks, 1);
+          if (int rcp = launch_iface_pack(p)) return rcp;
+        }
+        node_pass(csr_values, s.ks, s.ke, 0);
+        HIPCHK(hipGetLastError());
+        if (!box) break;
+        unsigned long long *fl = p->flags_host;
+        fl[1] = 0;
+        HIPCHK(hipMemcpyAsync(fl + 1, p->bad + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, p->stream));
+        HIPCHK(hipStreamSynchronize(p->stream));
+        if (!fl[1]) break;
+        p->fast_level = 0;  // general hexahedra or per-Gauss-point material: the general form, from now on
+        HIPCHK(hipMemsetAsync(p->bad, 0, 4 * sizeof(unsigned long long), p->stream));
       }
-      node_pass(csr_values, s.ks, s.ke, 0);
-      HIPCHK(hipGetLastError());
     }
     for (int64_t L0 = s.els; two_phase && L0 < s.ele; L0 += chunk) {
       const int64_t L1 = (L0 + chunk < s.ele) ? L0 + chunk : s.ele;
