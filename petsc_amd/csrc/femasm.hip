@@ -703,11 +703,17 @@ void launch_enr_elem(femasm_plan *p, const EnrArgs &a, int64_t nelem, bool mfma)
   hipLaunchKernelGGL((k_enr_elem<S, false>), grid, dim3(64 * NW), 0, p->stream, p->s, a);
 }
 
-template <int S, bool BOX>
+template <int S>
 void launch_enr_node(femasm_plan *p, const EnrArgs &a, int64_t nnodes) {
-  constexpr int per_wg = EnrNodeCfg<S, BOX>::NW * EnrNodeCfg<S, BOX>::NPW;
+  constexpr int per_wg = EnrNodeCfg<S>::NW * EnrNodeCfg<S>::NPW;
   const dim3 grid((unsigned)((nnodes + per_wg - 1) / per_wg));
-  hipLaunchKernelGGL((k_enr_node<S, BOX>), grid, dim3(64 * EnrNodeCfg<S, BOX>::NW), 0, p->stream, p->s, a);
+  hipLaunchKernelGGL((k_enr_node<S>), grid, dim3(64 * EnrNodeCfg<S>::NW), 0, p->stream, p->s, a);
+}
+template <int S>
+void launch_enr_box(femasm_plan *p, const EnrArgs &a, int64_t nnodes) {
+  constexpr int per_wg = EnrBoxCfg<S>::NW * EnrBoxCfg<S>::NPW;
+  const dim3 grid((unsigned)((nnodes + per_wg - 1) / per_wg));
+  hipLaunchKernelGGL((k_enr_box<S>), grid, dim3(64 * EnrBoxCfg<S>::NW), 0, p->stream, p->s, a);
 }
 
 int assemble_enriched(femasm_plan *p, const femasm_material *mat, int bc, double *csr_values, double *b,
@@ -800,17 +806,17 @@ int assemble_enriched(femasm_plan *p, const femasm_material *mat, int bc, double
       const int64_t nn = M * N * (l1 - l0);
       if (box) {
         switch (S) {
-          case 1: launch_enr_node<1, true>(p, g, nn); break;
-          case 2: launch_enr_node<2, true>(p, g, nn); break;
-          case 3: launch_enr_node<3, true>(p, g, nn); break;
-          default: launch_enr_node<4, true>(p, g, nn); break;
+          case 1: launch_enr_box<1>(p, g, nn); break;
+          case 2: launch_enr_box<2>(p, g, nn); break;
+          case 3: launch_enr_box<3>(p, g, nn); break;
+          default: launch_enr_box<4>(p, g, nn); break;
         }
       } else {
         switch (S) {
-          case 1: launch_enr_node<1, false>(p, g, nn); break;
-          case 2: launch_enr_node<2, false>(p, g, nn); break;
-          case 3: launch_enr_node<3, false>(p, g, nn); break;
-          default: launch_enr_node<4, false>(p, g, nn); break;
+          case 1: launch_enr_node<1>(p, g, nn); break;
+          case 2: launch_enr_node<2>(p, g, nn); break;
+          case 3: launch_enr_node<3>(p, g, nn); break;
+          default: launch_enr_node<4>(p, g, nn); break;
         }
       }
     };

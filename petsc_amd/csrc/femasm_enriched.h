@@ -427,12 +427,7 @@ __global__ __launch_bounds__(64 * ENR_GW) void k_enr_gather(const Slab s, const 
 // arithmetic); in exchange the kernel's HBM traffic is the CSR values plus the (cached) records.
 // Every CSR value has one writer and a fixed order of additions: bitwise reproducible.
 // ---------------------------------------------------------------------------
-// BOX (kernel level 2 of this kind, round 3): the mesh is rectilinear (k_check_rectilinear's verdict) and every element
-// has ONE (E, nu) over its Gauss points (tested bitwise in phase 1, flag bad[1] -> the general form).  Then J is diagonal,
-// grad N_b(p) = G[p][.][b] / J_rr needs no table (T is gone: 12.8 KB of the wave's 20 KB), and the material leaves the
-// Gauss-point loop as in k_assemble_s3_hex2: W^{st}[i][j] = sum_p (w detJ d_i Phi_{a,s}) d_j Phi_{b,t}, 9 FMAs per block
-// and point, then K^{st}[i][j] = c12 W[i][j] + c44 W[j][i], K[i][i] = c11 W[i][i] + c44 (W[j][j] + W[k][k]) once.
-template <int S, bool BOX = false> struct EnrNodeCfg {
+template <int S> struct EnrNodeCfg {
   static constexpr int NE = S - 1, D = 3 * S;
   static constexpr int SB = (S <= 2) ? S : 1;          // row families per contraction pass (9 S SB accumulators)
   static constexpr bool ALIAS = (SB == S);             // stage + block reuse the T/U area (single pass only)
@@ -443,46 +438,37 @@ template <int S, bool BOX = false> struct EnrNodeCfg {
                                                        // accesses of 16 consecutive lanes fall on 16 distinct bank pairs
                                                        // both when lanes (e, p) write and when lanes (e, b) read
   static constexpr int UES = 8 * UWP + 2;
-  // BOX: per element [1/J_00, 1/J_11, 1/J_22, c11, c12, c44, -, -], then per Gauss point (phi, grad phi) per family and
-  // the w detJ scaled gradients of the row node's S functions
-  static constexpr int BUP = (4 * NE + 3 * S + 1) & ~1, BUE = 8 + 8 * BUP + 2;
-  static constexpr int IN = BOX ? 8 * BUE : 8 * TES + 8 * UES;
-  static constexpr int STG = BOX ? 0 : 64 * 9 * S, ACC = 27 * D * D;  // (BOX: the lanes of a neighbour meet in registers)
+  static constexpr int IN = 8 * TES + 8 * UES;
+  static constexpr int STG = 64 * 9 * S, ACC = 27 * D * D;
   static constexpr int OUT = (STG + ACC + 1) & ~1;
   static constexpr int PER_WAVE = ALIAS ? (IN > OUT ? IN : OUT) : IN + OUT;
-  static constexpr int NW = (S <= 2) ? (BOX ? 12 : 8) : 2;    // waves per workgroup (LDS: 20 KB per wave for S = 2; BOX: 17 KB)
+  static constexpr int NW = (S <= 2) ? 8 : 2;          // waves per workgroup (LDS: 20 KB per wave for S = 2)
   static constexpr int NPW = 8;                        // consecutive nodes per wave
   static constexpr int NV = 72 * S, NIT = (NV + 63) / 64;  // values of one element and row family, rounds of 64 lanes
 };
 
-template <int S, bool BOX>
-__global__ __launch_bounds__((64 * EnrNodeCfg<S, BOX>::NW)) void k_enr_node(const Slab s, const EnrArgs a) {
-  using Cf = EnrNodeCfg<S, BOX>;
-  constexpr int BUP = Cf::BUP, BUE = Cf::BUE;
+template <int S>
+__global__ __launch_bounds__(64 * EnrNodeCfg<S>::NW) void k_enr_node(const Slab s, const EnrArgs a) {
+  using Cf = EnrNodeCfg<S>;
   constexpr int NE = Cf::NE, D = Cf::D, NW = Cf::NW, SB = Cf::SB, TES = Cf::TES, TPS = Cf::TPS, UES = Cf::UES, UWP = Cf::UWP;
   constexpr int NIT = Cf::NIT, NV = Cf::NV, RO = 3 + 4 * NE;  // RO: row gradients inside a U record
   __shared__ __attribute__((aligned(16))) double sh_w[NW][Cf::PER_WAVE];
   __shared__ double sh_G[8][3][8], sh_N[8][8];
-  const int tid = threadIdx.x, lane = tid & 63, w = BOX ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;  // (BOX: scalar node indices)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (int t = tid; t < 192; t += 64 * NW) (&sh_G[0][0][0])[t] = (&c_tab3.G[0][0][0])[t];
   for (int t = tid; t < 64; t += 64 * NW) (&sh_N[0][0])[t] = (&c_tab3.N[0][0])[t];
   __syncthreads();  // (the only workgroup barrier)
   double *T = sh_w[w], *U = T + 8 * TES;
   // activity flag of node n of element el: the 25th double of its T record of Gauss point n
   auto act_of = [&](int el, int n) { return reinterpret_cast<int *>(T + el * TES + n * TPS + 24); };
-  double *stg = Cf::ALIAS ? T : T + Cf::IN, *acc = stg + Cf::STG;
+  double *stg = Cf::ALIAS ? T : U + 8 * UES, *acc = stg + Cf::STG;
   auto wave_sync = [&]() {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
   };
   const int64_t M = s.dim[0], N = s.dim[1], P = s.dim[2];
   const int64_t mx = M - 1, my = N - 1;
-  // lane = (element e of the 8 around the node, column node b); phase 1: Gauss point p = b.
-  // BOX: two bits per axis, (element side, node side) = f >> 1, f & 1 -- the two lanes that meet in the neighbour at offset
-  // 0 of an axis are then f = 1 and f = 2 of that field: one quad permute along x, one row shift along y
-  const int fx = lane & 3, fy = (lane >> 2) & 3, fz = lane >> 4;
-  const int e = BOX ? (fx >> 1) + 2 * (fy >> 1) + 4 * (fz >> 1) : lane >> 3;
-  const int b = BOX ? hex_idx(fx & 1, fy & 1, fz & 1) : lane & 7;
+  const int e = lane >> 3, b = lane & 7;  // phase 1: Gauss point p = b
   const int ox = (e & 1) - 1, oy = ((e >> 1) & 1) - 1, oz = (e >> 2) - 1;
   const int arow = 4 * (-oz) + ((-ox) == 0 ? ((-oy) == 0 ? 0 : 1) : ((-oy) == 0 ? 3 : 2));  // hex_idx(-ox, -oy, -oz)
   // node-independent decode of the reduction rounds: position u = lane + 64 it of an element's 8 x 9 S staged values
@@ -498,19 +484,9 @@ __global__ __launch_bounds__((64 * EnrNodeCfg<S, BOX>::NW)) void k_enr_node(cons
   }
   const int64_t nn = M * N * (a.s1 - a.s0);
   const int64_t q0 = ((int64_t)blockIdx.x * NW + w) * Cf::NPW;
-  // (the wave's nodes are consecutive in the natural order: decoded once, then advanced -- three 64-bit divisions per
-  // node were a third of the kernel's scalar instructions)
-  int ii = (int)(q0 % M), jj = (int)((q0 / M) % N), kk_ = (int)(a.s0 + q0 / (M * N));
-  const int nq = (int)((nn - q0 < Cf::NPW) ? (nn - q0 > 0 ? nn - q0 : 0) : Cf::NPW);
 #pragma unroll 1
-  for (int qi = 0; qi < nq; qi++, ii++) {
-    if (ii == (int)M) {
-      ii = 0;
-      if (++jj == (int)N) jj = 0, kk_++;
-    }
-    // (the general form keeps its divisions: with the advanced indices it measured 3 % slower, the box form 5 % faster)
-    const int64_t qq_ = q0 + qi;
-    const int64_t i = BOX ? (int64_t)ii : qq_ % M, j = BOX ? (int64_t)jj : (qq_ / M) % N, k = BOX ? (int64_t)kk_ : a.s0 + qq_ / (M * N);
+  for (int64_t q = q0; q < q0 + Cf::NPW && q < nn; q++) {
+    const int64_t i = q % M, j = (q / M) % N, k = a.s0 + q / (M * N);
     const int cntx = span1(i, M), cnty = span1(j, N), cntz = span1(k, P);
     const int rowlen = cntx * cnty * cntz * D, nvals = D * rowlen;
     const int xi0 = (i == 0), yi0 = (j == 0), zi0 = (k == 0);
@@ -523,67 +499,7 @@ __global__ __launch_bounds__((64 * EnrNodeCfg<S, BOX>::NW)) void k_enr_node(cons
     const int64_t ezc = ez < s.els ? s.els : (ez >= s.ele ? s.ele - 1 : ez);
     const double *rec = a.gp + (exc + mx * (eyc + my * (ezc - s.mat_e_ks))) * (int64_t)a.stride;
     int actp = 0;
-    if constexpr (BOX) {
-      // ---- phase 1, box elements: lane (e, p) ----
-      const int p = b;
-      double *Ue = T + e * BUE, *Up = Ue + 8 + p * BUP;
-      // the element's box from its (-,-,-) and (+,+,+) nodes (the mesh is rectilinear: k_check_rectilinear)
-      const double *xa = a.coords + 3 * (exc + M * (eyc + N * (ezc - s.cks)));
-      const double *xb = a.coords + 3 * ((exc + 1) + M * ((eyc + 1) + N * (ezc + 1 - s.cks)));
-      const double J0 = 0.5 * (xb[0] - xa[0]), J1 = 0.5 * (xb[1] - xa[1]), J2 = 0.5 * (xb[2] - xa[2]);
-      const double Ep = rec[96 + p], nup = rec[104 + p];
-      // premise: one (E, nu) per element -- every lane compares its Gauss point's pair with that of point 0
-      if (ok && !(Ep == rec[96] && nup == rec[104]) && !a.iface) atomicAdd(a.bad + 1, 1ULL);
-      const double wJ = 1.0 * (J0 * J1 * J2);
-      if (ok && e == 0 && !a.iface && !(wJ > 0.0)) atomicAdd(a.bad, 1ULL);
-      // 1 / J_rr: hardware reciprocal + two Newton steps (relative error ~1e-16; the quotient sequence costs three times
-      // the instructions, and the results of this level are compared with the reference's at 1e-13)
-      auto recip = [](double x) {
-        double r = __builtin_amdgcn_rcp(x);
-        r = fma(fma(-x, r, 1.0), r, r);
-        return fma(fma(-x, r, 1.0), r, r);
-      };
-      const double ai[3] = {recip(J0), recip(J1), recip(J2)};
-      if (p == 0) {
-        double c11 = 0.0, c12 = 0.0, c44 = 0.0;
-        scaled_coefs<KIND_ELASTIC>(Ep, nup, 1.0, c11, c12, c44);
-        Ue[0] = ai[0], Ue[1] = ai[1], Ue[2] = ai[2];
-        Ue[3] = c11, Ue[4] = c12, Ue[5] = c44;
-      }
-      // gradient of the row node's N at this point, scaled by w detJ (zero for an element that is not assembled here)
-      const double wz = ok ? wJ : 0.0;
-      const double r0[3] = {sh_G[p][0][arow] * ai[0], sh_G[p][1][arow] * ai[1], sh_G[p][2][arow] * ai[2]};
-      Up[4 * NE] = wz * r0[0], Up[4 * NE + 1] = wz * r0[1], Up[4 * NE + 2] = wz * r0[2];
-      if constexpr (NE > 0) {
-        actp = enr_active(rec, a.base, p, NE);
-        const int actr = enr_active(rec, a.base, arow, NE);
-        const double Nr = sh_N[p][arow];
-#pragma unroll
-        for (int m = 0; m < NE; m++) {
-          const double *en = rec + a.base + 64 * m;
-          double phi = en[8 + p], dphi[3] = {en[16 + 3 * p], en[16 + 3 * p + 1], en[16 + 3 * p + 2]};
-          if (a.sgfem) {
-            double sN = 0.0, sG[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-            for (int n = 0; n < 8; n++) {
-              const double pn = en[n];
-              sN = fma(sh_N[p][n], pn, sN);
-#pragma unroll
-              for (int kk = 0; kk < 3; kk++) sG[kk] = fma(sh_G[p][kk][n], pn, sG[kk]);
-            }
-            phi = phi - sN;
-#pragma unroll
-            for (int kk = 0; kk < 3; kk++) dphi[kk] = dphi[kk] - sG[kk] * ai[kk];
-          }
-          Up[4 * m] = phi;
-#pragma unroll
-          for (int kk = 0; kk < 3; kk++) Up[4 * m + 1 + kk] = dphi[kk];
-          const bool on = m < actr;
-#pragma unroll
-          for (int kk = 0; kk < 3; kk++) Up[4 * NE + 3 * (1 + m) + kk] = on ? wz * (phi * r0[kk] + Nr * dphi[kk]) : 0.0;
-        }
-      }
-    } else {
+    {
       const int p = b;
       double xs[24];
 #pragma unroll
@@ -692,56 +608,6 @@ __global__ __launch_bounds__((64 * EnrNodeCfg<S, BOX>::NW)) void k_enr_node(cons
           for (int t = 0; t < S; t++)
 #pragma unroll
             for (int v = 0; v < 9; v++) av[sa][t][v] = 0.0;
-        if constexpr (BOX) {
-          // ---- phase 2, box elements: W^{st}[i][j] over the eight Gauss points, then the material once ----
-          const double *Ue = T + e * BUE;
-          const double ai0 = Ue[0], ai1 = Ue[1], ai2 = Ue[2], c11 = Ue[3], c12 = Ue[4], c44 = Ue[5];
-#pragma unroll 2
-          for (int p = 0; p < 8; p++) {
-            const double *Up = Ue + 8 + p * BUP;
-            double G[S][3];
-            G[0][0] = sh_G[p][0][b] * ai0, G[0][1] = sh_G[p][1][b] * ai1, G[0][2] = sh_G[p][2][b] * ai2;
-            if constexpr (NE > 0) {
-              const double Nb = sh_N[p][b];
-#pragma unroll
-              for (int m = 0; m < NE; m++) {
-                const double phi = Up[4 * m];
-#pragma unroll
-                for (int kk = 0; kk < 3; kk++) G[1 + m][kk] = phi * G[0][kk] + Nb * Up[4 * m + 1 + kk];
-              }
-            }
-#pragma unroll
-            for (int sa = 0; sa < SB; sa++) {
-              const double *R = Up + 4 * NE + 3 * (s0 + sa);
-              const double l0 = R[0], l1 = R[1], l2 = R[2];
-#pragma unroll
-              for (int t = 0; t < S; t++) {
-                double *w = av[sa][t];
-                w[0] = fma(l0, G[t][0], w[0]); w[1] = fma(l0, G[t][1], w[1]); w[2] = fma(l0, G[t][2], w[2]);
-                w[3] = fma(l1, G[t][0], w[3]); w[4] = fma(l1, G[t][1], w[4]); w[5] = fma(l1, G[t][2], w[5]);
-                w[6] = fma(l2, G[t][0], w[6]); w[7] = fma(l2, G[t][1], w[7]); w[8] = fma(l2, G[t][2], w[8]);
-              }
-            }
-          }
-#pragma unroll
-          for (int sa = 0; sa < SB; sa++)
-#pragma unroll
-            for (int t = 0; t < S; t++) {
-              double *w = av[sa][t];
-              const bool on = t == 0 || (t - 1) < actp;  // an inactive family of column node b is zero on this element
-              const double d0 = w[0], d1 = w[4], d2 = w[8];
-              w[0] = on ? fma(c11, d0, c44 * (d1 + d2)) : 0.0;
-              w[4] = on ? fma(c11, d1, c44 * (d0 + d2)) : 0.0;
-              w[8] = on ? fma(c11, d2, c44 * (d0 + d1)) : 0.0;
-#pragma unroll
-              for (int pr = 0; pr < 3; pr++) {
-                const int ij = pr == 0 ? 1 : (pr == 1 ? 2 : 5), ji = pr == 0 ? 3 : (pr == 1 ? 6 : 7);
-                const double wij = w[ij], wji = w[ji];
-                w[ij] = on ? fma(c12, wij, c44 * wji) : 0.0;
-                w[ji] = on ? fma(c12, wji, c44 * wij) : 0.0;
-              }
-            }
-        } else
 #if FEMASM_EXP == 13 || FEMASM_EXP == 14  // profiling build: no contraction
 #pragma unroll 1
         for (int p = 0; p < 0; p++) {
@@ -791,46 +657,6 @@ __global__ __launch_bounds__((64 * EnrNodeCfg<S, BOX>::NW)) void k_enr_node(cons
             for (int v = 0; v < 9; v++) asm volatile("" ::"v"(av[sa][t][v]));
         continue;
 #endif
-        if constexpr (BOX) {
-          // The lanes whose blocks belong to one neighbour meet in registers along x and y (the partner's block through a
-          // quad permute / a row shift, added with a 0 / 1 factor so that every lane runs the same code; a fixed tree:
-          // deterministic) and in LDS along z: the lanes below the node write, then the lanes above it add in place (LDS
-          // executes a wave's accesses in order).  Every stored slot of the node's block has exactly one writing lane, so
-          // the block is not zeroed and nothing is staged.
-          const double mxs = (fx == 1) ? 1.0 : 0.0, mys = (fy == 1) ? 1.0 : 0.0;
-#pragma unroll
-          for (int sa = 0; sa < SB; sa++)
-#pragma unroll
-            for (int t = 0; t < S; t++)
-#pragma unroll
-              for (int v = 0; v < 9; v++) {
-                double &wv = av[sa][t][v];
-                wv = fma(mxs, quad_perm<0xD8>(wv), wv);   // fx = 1 takes fx = 2's
-                wv = fma(mys, quad_perm<0x104>(wv), wv);  // row_shl:4 -- fy = 1 takes fy = 2's
-              }
-          const int nbx = ox + (fx & 1), nby = oy + (fy & 1), nbz = oz + (fz & 1);  // the neighbour, offsets -1 .. 1
-          const bool exists = i + nbx >= 0 && i + nbx < M && j + nby >= 0 && j + nby < N && k + nbz >= 0 && k + nbz < P;
-          const bool hold = exists && fx != 2 && fy != 2;
-          const int nbpos = (((nbz + 1 - zi0) * cnty + (nby + 1 - yi0)) * cntx + (nbx + 1 - xi0)) * D;
-#pragma unroll
-          for (int pass = 0; pass < 2; pass++) {
-            if (hold && ((fz == 2) == (pass == 1))) {
-#pragma unroll
-              for (int sa = 0; sa < SB; sa++)
-#pragma unroll
-                for (int r = 0; r < 3; r++) {
-                  double *d = acc + (3 * (s0 + sa) + r) * rowlen + nbpos;
-#pragma unroll
-                  for (int t = 0; t < S; t++)
-#pragma unroll
-                    for (int c = 0; c < 3; c++)
-                      d[3 * t + c] = pass ? d[3 * t + c] + av[sa][t][3 * r + c] : av[sa][t][3 * r + c];
-                }
-            }
-            wave_sync();
-          }
-          continue;
-        }
         if (Cf::ALIAS) {
           for (int t = lane; t < nvals; t += 64) acc[t] = 0.0;
         }
@@ -904,6 +730,289 @@ __global__ __launch_bounds__((64 * EnrNodeCfg<S, BOX>::NW)) void k_enr_node(cons
       }
     }
     wave_sync();  // the next node's phase 1 overwrites the block
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Level 2 of this kind (round 3): k_enr_box<S>.  Premises, both tested on the device (flag bad[1] -> the plan falls back
+// to k_enr_node for good): the mesh is rectilinear (k_check_rectilinear's verdict before this kernel) and every element
+// has ONE (E, nu) over its Gauss points (compared bitwise in phase 1).  Then
+//   * J is diagonal and grad N_b(p) = G[p][.][b] / J_rr: no gradient table (12.8 KB of k_enr_node's 20 KB per wave), no
+//     3x3 inverse, 6 coordinates per element instead of 24;
+//   * the material leaves the Gauss-point loop as in k_assemble_s3_hex2: W^{st}[i][j] = sum_p (w detJ d_i Phi_{a,s})
+//     d_j Phi_{b,t} -- 9 FMAs per block and point -- then K^{st}[i][j] = c12 W[i][j] + c44 W[j][i],
+//     K^{st}[i][i] = c11 W[i][i] + c44 (W[j][j] + W[k][k]) once per block;
+//   * lane = two bits per axis, (element side, node side): the two lanes that meet in the neighbour at offset 0 of an
+//     axis are field values 1 and 2, so the blocks of a neighbour are added in REGISTERS along x (one quad permute) and
+//     along y (one row shift), with a 0 / 1 factor so that every lane runs the same code, and in LDS along z (the lanes
+//     below the node write, then the lanes above add in place: LDS executes a wave's accesses in order).  A fixed tree:
+//     deterministic.  Every stored slot of the node's block has exactly one writing lane: the block is not zeroed, nothing
+//     is staged, and the eight ordered rounds of k_enr_node (3.8 of its 11.7 ms at equal occupancy) are gone;
+//   * a wave keeps phase 1 of its NEXT node in front of the stores of this one (the element table and the node's block do
+//     not share LDS): gfx9 retires a wave's loads and stores through one in-order counter, so a load issued behind the
+//     block's eight stores waits for their acknowledgement (1.2 of 9.1 ms before this);
+//   * 13.4 KB of LDS per wave and <= 168 registers: 12 waves per CU (k_enr_node: 8).
+// ---------------------------------------------------------------------------
+template <int S> struct EnrBoxCfg {
+  static constexpr int NE = S - 1, D = 3 * S;
+  static constexpr int SB = (S <= 2) ? S : 1;  // row families per contraction pass (9 S SB accumulators)
+  // per element [1/J_00, 1/J_11, 1/J_22, c11, c12, c44, -, -], then per Gauss point (phi, grad phi) per family and the
+  // w detJ scaled gradients of the row node's S functions
+  static constexpr int BUP = (4 * NE + 3 * S + 1) & ~1, BUE = 8 + 8 * BUP;
+  static constexpr int IN = 8 * BUE, ACC = 27 * D * D;
+  static constexpr int PER_WAVE = (IN + ACC + 2 + 1) & ~1;
+  static constexpr int NWMAX = (160 * 1024 - 2048 - 512) / (8 * PER_WAVE);  // (2 KB: the reference tables)
+  static constexpr int NW = NWMAX > 12 ? 12 : NWMAX;  // waves per workgroup = per CU (12: three per SIMD at <= 168 registers)
+  static constexpr int NPW = 8;                       // consecutive nodes per wave
+};
+
+template <int S>
+__global__ __launch_bounds__((64 * EnrBoxCfg<S>::NW)) void k_enr_box(const Slab s, const EnrArgs a) {
+  using Cf = EnrBoxCfg<S>;
+  constexpr int NE = Cf::NE, D = Cf::D, NW = Cf::NW, SB = Cf::SB, BUP = Cf::BUP, BUE = Cf::BUE;
+  __shared__ __attribute__((aligned(16))) double sh_w[NW][Cf::PER_WAVE];
+  __shared__ double sh_G[8][3][8], sh_N[8][8];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar node indices)
+  for (int t = tid; t < 192; t += 64 * NW) (&sh_G[0][0][0])[t] = (&c_tab3.G[0][0][0])[t];
+  for (int t = tid; t < 64; t += 64 * NW) (&sh_N[0][0])[t] = (&c_tab3.N[0][0])[t];
+  __syncthreads();  // (the only workgroup barrier)
+  double *U = sh_w[w], *acc0 = U + Cf::IN;
+  auto wave_sync = [&]() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  };
+  const int64_t M = s.dim[0], N = s.dim[1], P = s.dim[2];
+  const int64_t mx = M - 1, my = N - 1;
+  const int fx = lane & 3, fy = (lane >> 2) & 3, fz = lane >> 4;
+  const int e = (fx >> 1) + 2 * (fy >> 1) + 4 * (fz >> 1);  // element of the 8 around the node, k -> j -> i order
+  const int b = hex_idx(fx & 1, fy & 1, fz & 1);            // column node of that element; phase 1: Gauss point p = b
+  const int ox = (e & 1) - 1, oy = ((e >> 1) & 1) - 1, oz = (e >> 2) - 1;
+  const int arow = hex_idx(-ox, -oy, -oz);  // the node itself in element e
+  const int64_t nn = M * N * (a.s1 - a.s0);
+  const int64_t q0 = ((int64_t)blockIdx.x * NW + w) * Cf::NPW;
+  const int nq = (int)((nn - q0 < Cf::NPW) ? (nn - q0 > 0 ? nn - q0 : 0) : Cf::NPW);
+  // (the wave's nodes are consecutive in the natural order: decoded once, then advanced)
+  int ii = (int)(q0 % M), jj = (int)((q0 / M) % N), kk_ = (int)(a.s0 + q0 / (M * N));
+  int actp = 0;
+
+  // ---- phase 1, lane (e, p): the element's box, premise, coefficients, (phi, grad phi), the row node's gradients ----
+  auto phase1 = [&](int64_t i, int64_t j, int64_t k) {
+    const int p = b;
+    const int64_t ex = i + ox, ey = j + oy, ez = k + oz;
+    const bool ok = !(ex < 0 || ex >= mx || ey < 0 || ey >= my || ez < s.els || ez >= s.ele);
+    const int64_t exc = ex < 0 ? 0 : (ex >= mx ? mx - 1 : ex), eyc = ey < 0 ? 0 : (ey >= my ? my - 1 : ey);
+    const int64_t ezc = ez < s.els ? s.els : (ez >= s.ele ? s.ele - 1 : ez);
+    const double *rec = a.gp + (exc + mx * (eyc + my * (ezc - s.mat_e_ks))) * (int64_t)a.stride;
+    double *Ue = U + e * BUE, *Up = Ue + 8 + p * BUP;
+    // the element's box from its (-,-,-) and (+,+,+) nodes (the mesh is rectilinear: k_check_rectilinear)
+    const double *xa = a.coords + 3 * (exc + M * (eyc + N * (ezc - s.cks)));
+    const double *xb = a.coords + 3 * ((exc + 1) + M * ((eyc + 1) + N * (ezc + 1 - s.cks)));
+    const double J0 = 0.5 * (xb[0] - xa[0]), J1 = 0.5 * (xb[1] - xa[1]), J2 = 0.5 * (xb[2] - xa[2]);
+    const double Ep = rec[96 + p], nup = rec[104 + p];
+    // premise: one (E, nu) per element -- every lane compares its Gauss point's pair with that of point 0
+    if (ok && !(Ep == rec[96] && nup == rec[104]) && !a.iface) atomicAdd(a.bad + 1, 1ULL);
+    const double wJ = 1.0 * (J0 * J1 * J2);
+    // the element is counted once, by the wave of its local node 6 (always an owned node of this rank)
+    if (ok && e == 0 && !a.iface && !(wJ > 0.0)) atomicAdd(a.bad, 1ULL);
+    // 1 / J_rr: hardware reciprocal + two Newton steps (relative error ~1e-16; the quotient sequence costs three times
+    // the instructions, and the results of this level are compared with the reference's at 1e-13)
+    auto recip = [](double x) {
+      double r = __builtin_amdgcn_rcp(x);
+      r = fma(fma(-x, r, 1.0), r, r);
+      return fma(fma(-x, r, 1.0), r, r);
+    };
+    const double ai[3] = {recip(J0), recip(J1), recip(J2)};
+    if (p == 0) {
+      double c11 = 0.0, c12 = 0.0, c44 = 0.0;
+      scaled_coefs<KIND_ELASTIC>(Ep, nup, 1.0, c11, c12, c44);
+      Ue[0] = ai[0], Ue[1] = ai[1], Ue[2] = ai[2];
+      Ue[3] = c11, Ue[4] = c12, Ue[5] = c44;
+    }
+    // gradient of the row node's N at this point, scaled by w detJ (zero for an element that is not assembled here)
+    const double wz = ok ? wJ : 0.0;
+    const double r0[3] = {sh_G[p][0][arow] * ai[0], sh_G[p][1][arow] * ai[1], sh_G[p][2][arow] * ai[2]};
+    Up[4 * NE] = wz * r0[0], Up[4 * NE + 1] = wz * r0[1], Up[4 * NE + 2] = wz * r0[2];
+    if constexpr (NE > 0) {
+      actp = enr_active(rec, a.base, p, NE);
+      const int actr = enr_active(rec, a.base, arow, NE);
+      const double Nr = sh_N[p][arow];
+#pragma unroll
+      for (int m = 0; m < NE; m++) {
+        const double *en = rec + a.base + 64 * m;
+        double phi = en[8 + p], dphi[3] = {en[16 + 3 * p], en[16 + 3 * p + 1], en[16 + 3 * p + 2]};
+        if (a.sgfem) {
+          double sN = 0.0, sG[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+          for (int n = 0; n < 8; n++) {
+            const double pn = en[n];
+            sN = fma(sh_N[p][n], pn, sN);
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++) sG[kk] = fma(sh_G[p][kk][n], pn, sG[kk]);
+          }
+          phi = phi - sN;
+#pragma unroll
+          for (int kk = 0; kk < 3; kk++) dphi[kk] = dphi[kk] - sG[kk] * ai[kk];
+        }
+        Up[4 * m] = phi;
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) Up[4 * m + 1 + kk] = dphi[kk];
+        const bool on = m < actr;
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) Up[4 * NE + 3 * (1 + m) + kk] = on ? wz * (phi * r0[kk] + Nr * dphi[kk]) : 0.0;
+      }
+    }
+  };
+
+  if (nq > 0) phase1(ii, jj, kk_);
+#pragma unroll 1
+  for (int qi = 0; qi < nq; qi++) {
+    const int64_t i = ii, j = jj, k = kk_;
+    const int cntx = span1(i, M), cnty = span1(j, N), cntz = span1(k, P);
+    const int rowlen = cntx * cnty * cntz * D, nvals = D * rowlen;
+    const int xi0 = (i == 0), yi0 = (j == 0), zi0 = (k == 0);
+    const bool dirichlet = (a.bc == BC_S3) && on_boundary(s, i, j, k);
+    const int self = (((k > 0) * cnty + (j > 0)) * cntx + (i > 0)) * D;
+    // the node's block in the CSR array; its LDS copy starts at the parity of its HBM address, so that a 16-byte chunk of
+    // HBM is a 16-byte chunk of LDS (ds_read_b128 in the copy-out)
+    double *o = a.out + (row_start(s, i, j, k, 0) - a.base_off);
+    const int head = (int)((reinterpret_cast<uintptr_t>(o) >> 3) & 15);
+    double *acc = acc0 + (head & 1);
+    wave_sync();  // the element table of this node is complete
+
+    if (!dirichlet) {
+#pragma unroll 1
+      for (int s0 = 0; s0 < S; s0 += SB) {
+        // ---- phase 2, lane (e, b): W^{st}[i][j] over the eight Gauss points, then the material once ----
+        double av[SB][S][9];
+#pragma unroll
+        for (int sa = 0; sa < SB; sa++)
+#pragma unroll
+          for (int t = 0; t < S; t++)
+#pragma unroll
+            for (int v = 0; v < 9; v++) av[sa][t][v] = 0.0;
+        const double *Ue = U + e * BUE;
+        const double ai0 = Ue[0], ai1 = Ue[1], ai2 = Ue[2], c11 = Ue[3], c12 = Ue[4], c44 = Ue[5];
+#pragma unroll 2
+        for (int p = 0; p < 8; p++) {
+          const double *Up = Ue + 8 + p * BUP;
+          double G[S][3];
+          G[0][0] = sh_G[p][0][b] * ai0, G[0][1] = sh_G[p][1][b] * ai1, G[0][2] = sh_G[p][2][b] * ai2;
+          if constexpr (NE > 0) {
+            const double Nb = sh_N[p][b];
+#pragma unroll
+            for (int m = 0; m < NE; m++) {
+              const double phi = Up[4 * m];
+#pragma unroll
+              for (int kk = 0; kk < 3; kk++) G[1 + m][kk] = phi * G[0][kk] + Nb * Up[4 * m + 1 + kk];
+            }
+          }
+#pragma unroll
+          for (int sa = 0; sa < SB; sa++) {
+            const double *R = Up + 4 * NE + 3 * (s0 + sa);
+            const double l0 = R[0], l1 = R[1], l2 = R[2];
+#pragma unroll
+            for (int t = 0; t < S; t++) {
+              double *wv = av[sa][t];
+              wv[0] = fma(l0, G[t][0], wv[0]); wv[1] = fma(l0, G[t][1], wv[1]); wv[2] = fma(l0, G[t][2], wv[2]);
+              wv[3] = fma(l1, G[t][0], wv[3]); wv[4] = fma(l1, G[t][1], wv[4]); wv[5] = fma(l1, G[t][2], wv[5]);
+              wv[6] = fma(l2, G[t][0], wv[6]); wv[7] = fma(l2, G[t][1], wv[7]); wv[8] = fma(l2, G[t][2], wv[8]);
+            }
+          }
+        }
+#pragma unroll
+        for (int sa = 0; sa < SB; sa++)
+#pragma unroll
+          for (int t = 0; t < S; t++) {
+            double *wv = av[sa][t];
+            const bool on = t == 0 || (t - 1) < actp;  // an inactive family of column node b is zero on this element
+            const double d0 = wv[0], d1 = wv[4], d2 = wv[8];
+            wv[0] = on ? fma(c11, d0, c44 * (d1 + d2)) : 0.0;
+            wv[4] = on ? fma(c11, d1, c44 * (d0 + d2)) : 0.0;
+            wv[8] = on ? fma(c11, d2, c44 * (d0 + d1)) : 0.0;
+#pragma unroll
+            for (int pr = 0; pr < 3; pr++) {
+              const int ij = pr == 0 ? 1 : (pr == 1 ? 2 : 5), ji = pr == 0 ? 3 : (pr == 1 ? 6 : 7);
+              const double wij = wv[ij], wji = wv[ji];
+              wv[ij] = on ? fma(c12, wij, c44 * wji) : 0.0;
+              wv[ji] = on ? fma(c12, wji, c44 * wij) : 0.0;
+            }
+          }
+        // ---- phase 3: the lanes of a neighbour meet in registers along x and y, in LDS along z ----
+        const double mxs = (fx == 1) ? 1.0 : 0.0, mys = (fy == 1) ? 1.0 : 0.0;
+#pragma unroll
+        for (int sa = 0; sa < SB; sa++)
+#pragma unroll
+          for (int t = 0; t < S; t++)
+#pragma unroll
+            for (int v = 0; v < 9; v++) {
+              double &wv = av[sa][t][v];
+              wv = fma(mxs, quad_perm<0xD8>(wv), wv);   // fx = 1 takes fx = 2's
+              wv = fma(mys, quad_perm<0x104>(wv), wv);  // row_shl:4 -- fy = 1 takes fy = 2's
+            }
+        const int nbx = ox + (fx & 1), nby = oy + (fy & 1), nbz = oz + (fz & 1);  // the neighbour, offsets -1 .. 1
+        const bool exists = i + nbx >= 0 && i + nbx < M && j + nby >= 0 && j + nby < N && k + nbz >= 0 && k + nbz < P;
+        const bool hold = exists && fx != 2 && fy != 2;
+        const int nbpos = (((nbz + 1 - zi0) * cnty + (nby + 1 - yi0)) * cntx + (nbx + 1 - xi0)) * D;
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+          if (hold && ((fz == 2) == (pass == 1))) {
+#pragma unroll
+            for (int sa = 0; sa < SB; sa++)
+#pragma unroll
+              for (int r = 0; r < 3; r++) {
+                double *d = acc + (3 * (s0 + sa) + r) * rowlen + nbpos;
+#pragma unroll
+                for (int t = 0; t < S; t++)
+#pragma unroll
+                  for (int c = 0; c < 3; c++)
+                    d[3 * t + c] = pass ? d[3 * t + c] + av[sa][t][3 * r + c] : av[sa][t][3 * r + c];
+              }
+          }
+          wave_sync();
+        }
+      }
+    } else {
+      for (int t = lane; t < nvals; t += 64) acc[t] = 0.0;
+      wave_sync();
+    }
+    // ---- row rules: Dirichlet faces (all dofs of the node), blocked redundant dofs ----
+    {
+      int nact = NE;
+      if (!dirichlet && NE > 0 && !a.iface) {
+        const int64_t bx = i > 0 ? i - 1 : 0, by = j > 0 ? j - 1 : 0, bz = k > 0 ? k - 1 : 0;  // the element behind the node
+        const double *rb = a.gp + (bx + mx * (by + my * (bz - s.mat_e_ks))) * (int64_t)a.stride;
+        nact = enr_active(rb, a.base, hex_idx(i > 0, j > 0, k > 0), NE);
+      }
+      const double diag = a.iface ? 0.0 : 1.0;
+      const int qfirst = dirichlet ? 0 : 3 * (1 + nact);  // rows [qfirst, D) become unit rows
+      if (dirichlet || !a.iface) {
+        for (int qr = qfirst; qr < D; qr++)
+          for (int t = lane; t < rowlen; t += 64) acc[qr * rowlen + t] = (t == self + qr) ? diag : 0.0;
+      }
+    }
+    wave_sync();
+    // ---- the next node's phase 1 BEFORE this node's stores (see the header) ----
+    if (++ii == (int)M) {
+      ii = 0;
+      if (++jj == (int)N) jj = 0, kk_++;
+    }
+    if (qi + 1 < nq) phase1(ii, jj, kk_);
+    // ---- the block -> CSR array, 16 B per lane from the 128-byte boundary below it ----
+    for (int t0 = -head; t0 < nvals; t0 += 128) {
+      const int t = t0 + 2 * lane;
+      if (t >= 0 && t + 1 < nvals) {
+        const double2 v = *reinterpret_cast<const double2 *>(acc + t);  // 16-byte aligned: t + (head & 1) is even
+#if FEMASM_EXP == 11  // profiling build: no global stores
+        asm volatile("" ::"v"(v.x), "v"(v.y));
+        continue;
+#endif
+        store_pair(o + t, v);
+      } else if (t + 1 >= 0 && t + 1 < nvals && t < 0) {
+        o[t + 1] = acc[t + 1];
+      } else if (t >= 0 && t < nvals) {
+        o[t] = acc[t];
+      }
+    }
   }
 }
 
