@@ -253,7 +253,7 @@ HEX_FLOPS_PER_ELEMENT = 8 * (2 * 72 + 60 + 2 * 72 + 96 + 64 * 2 * 9 + 24) + 64 *
 def kernel_name(wl, level, args):
     if wl == "enriched3d":
         mode = args.enr_contraction if args.enr_contraction != "default" else "node"
-        return (f"k_enr_node<S={1 + args.n_enr}>" if mode == "node" else
+        return ((f"k_enr_box<S={1 + args.n_enr}>" if level == 2 else f"k_enr_node<S={1 + args.n_enr}>") if mode == "node" else
                 f"k_enr_elem<S={1 + args.n_enr},{mode}> + k_enr_gather (all of K)")
     if wl == "elastic2d":
         return "k_assemble_e2_rect" if level == 2 else "k_assemble_ke_e2"

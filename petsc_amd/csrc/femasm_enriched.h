@@ -51,6 +51,7 @@ struct EnrArgs {
   int32_t stride, base;   // record stride and width of the R3 part (408: 32-bit PetscInt, 416: 64-bit)
   int32_t sgfem;          // 1: phi = psi - I_h psi (R3:42 `type` 1), 0: phi = psi
   int32_t bc, iface;
+  int32_t npw;            // k_enr_box: consecutive nodes per wave
   double E, nu;           // FEMASM_MAT_UNIFORM is not offered for this kind (the enrichment data lives in the records)
 };
 
@@ -763,7 +764,7 @@ template <int S> struct EnrBoxCfg {
   static constexpr int PER_WAVE = (IN + ACC + 2 + 1) & ~1;
   static constexpr int NWMAX = (160 * 1024 - 2048 - 512) / (8 * PER_WAVE);  // (2 KB: the reference tables)
   static constexpr int NW = NWMAX > 12 ? 12 : NWMAX;  // waves per workgroup = per CU (12: three per SIMD at <= 168 registers)
-  static constexpr int NPW = 8;                       // consecutive nodes per wave
+  static constexpr int NPW_MAX = 32;                  // consecutive nodes per wave (EnrArgs::npw: set by the launch)
 };
 
 template <int S>
@@ -789,8 +790,8 @@ __global__ __launch_bounds__((64 * EnrBoxCfg<S>::NW)) void k_enr_box(const Slab 
   const int ox = (e & 1) - 1, oy = ((e >> 1) & 1) - 1, oz = (e >> 2) - 1;
   const int arow = hex_idx(-ox, -oy, -oz);  // the node itself in element e
   const int64_t nn = M * N * (a.s1 - a.s0);
-  const int64_t q0 = ((int64_t)blockIdx.x * NW + w) * Cf::NPW;
-  const int nq = (int)((nn - q0 < Cf::NPW) ? (nn - q0 > 0 ? nn - q0 : 0) : Cf::NPW);
+  const int64_t q0 = ((int64_t)blockIdx.x * NW + w) * a.npw;
+  const int nq = (int)((nn - q0 < a.npw) ? (nn - q0 > 0 ? nn - q0 : 0) : a.npw);
   // (the wave's nodes are consecutive in the natural order: decoded once, then advanced)
   int ii = (int)(q0 % M), jj = (int)((q0 / M) % N), kk_ = (int)(a.s0 + q0 / (M * N));
   int actp = 0;

@@ -10,5 +10,6 @@ bash $R/scripts/make_profiles.sh elastic3d_general --perturb > $R/gpurun_out/mp_
 bash $R/scripts/make_profiles.sh poisson3d_general --workload poisson3d --perturb > $R/gpurun_out/mp_p3g.log 2>&1; echo poisson3d_general done
 bash $R/scripts/make_profiles.sh elastic2d_general --workload elastic2d --perturb > $R/gpurun_out/mp_e2g.log 2>&1; echo elastic2d_general done
 bash $R/scripts/make_profiles.sh enriched3d --workload enriched3d > $R/gpurun_out/mp_enr.log 2>&1; echo enriched3d done
+bash $R/scripts/make_profiles.sh enriched3d_general --workload enriched3d --perturb > $R/gpurun_out/mp_enrg.log 2>&1; echo enriched3d_general done
 bash $R/scripts/make_profiles.sh enriched3d_valu --workload enriched3d --enr-contraction valu > $R/gpurun_out/mp_enrv.log 2>&1; echo enriched3d_valu done
 bash $R/scripts/make_profiles.sh enriched3d_mfma --workload enriched3d --enr-contraction mfma > $R/gpurun_out/mp_enrm.log 2>&1; echo enriched3d_mfma done

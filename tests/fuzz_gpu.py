@@ -216,7 +216,7 @@ def main():
                 break
         mesh = str(rng.choice(["uniform", "graded", "graded", "sheared", "perturbed"]))
         material = "none" if kind == "p3" else str(rng.choice(["constant", "element", "element", "gp"]))
-        if kind == "enr" and mesh in ("graded", "sheared"):
+        if kind == "enr" and mesh == "sheared":
             mesh = "perturbed"
         use_async = bool(rng.integers(0, 2))
         SL = dims[-1]

@@ -31,11 +31,23 @@ PSI = [
 ]
 
 
-def make_case(env, dims, n_enr, perturb=True, sgfem=1, base=408, partial=False, vary=True, dirichlet=True, seed=3):
+def graded_axis(rng, n):
+    h = rng.uniform(0.5, 1.5, size=n - 1)
+    x = np.concatenate([[0.0], np.cumsum(h)])
+    return x / x[-1]
+
+
+def make_case(env, dims, n_enr, perturb=True, sgfem=1, base=408, partial=False, vary=True, dirichlet=True, seed=3,
+              graded=False):
+    """vary: True = (E, nu) per Gauss point, "element" = one pair per element (the premise of the box level), False =
+    the fill's constants; graded: a rectilinear mesh with random spacings (perturb must be False)"""
     O = env["O"]
     M, N, P = dims
     rng = np.random.default_rng(seed)
     coords = O.uniform_coords(3, M, N, P)
+    if graded:
+        z, y, x = np.meshgrid(graded_axis(rng, P), graded_axis(rng, N), graded_axis(rng, M), indexing="ij")
+        coords = np.ascontiguousarray(np.stack([x, y, z], axis=-1).reshape(-1))
     if perturb:
         coords = O.perturb_coords(coords, 3, M, N, P)
     et = ne = None
@@ -46,8 +58,9 @@ def make_case(env, dims, n_enr, perturb=True, sgfem=1, base=408, partial=False, 
     stride = O.enr_stride(n_enr, base)
     if vary:
         pr = props.reshape(-1, stride)
-        pr[:, 96:104] = rng.uniform(50, 150, size=(pr.shape[0], 8))
-        pr[:, 104:112] = rng.uniform(0.1, 0.4, size=(pr.shape[0], 8))
+        ngp = 1 if vary == "element" else 8
+        pr[:, 96:104] = rng.uniform(50, 150, size=(pr.shape[0], ngp))
+        pr[:, 104:112] = rng.uniform(0.1, 0.4, size=(pr.shape[0], ngp))
         pr[:, 112:136] = rng.uniform(50, 150, size=(pr.shape[0], 24))
         pr[:, 136:160] = rng.uniform(0.1, 0.4, size=(pr.shape[0], 24))
         pr[:, 184:400] = rng.uniform(-1, 1, size=(pr.shape[0], 216))
@@ -105,6 +118,80 @@ def test_partial_enrichment_gfem_and_64bit_flags(env, mode, sgfem, base, dirichl
     plan, vals, b = gpu_assemble(env, case2, 2 if mode == 2 else 0)
     assert rel(vals, case2["K"]) <= TOL and rel(b, case2["b"]) <= TOL
     plan.close()
+
+
+@pytest.mark.parametrize("dims,n_enr", [((4, 4, 4), 1), ((6, 5, 7), 1), ((13, 6, 5), 1), ((5, 4, 4), 2), ((4, 3, 5), 3),
+                                        ((2, 2, 2), 1), ((9, 3, 4), 0), ((3, 10, 3), 2), ((35, 4, 3), 1)])
+@pytest.mark.parametrize("graded", [False, True])
+def test_box_level_rectilinear_mesh_one_material_per_element(env, dims, n_enr, graded):
+    """k_enr_box (level 2 of the enriched kind): rectilinear mesh, one (E, nu) per element that differs from element to
+    element; the plan must stay at level 2 and K, b match the restatement's per-Gauss-point loops."""
+    case = make_case(env, dims, n_enr, perturb=False, graded=graded, vary="element")
+    plan, vals, b = gpu_assemble(env, case)
+    assert plan.fast_path() == 2
+    assert not np.isnan(vals).any() and not np.isnan(b).any()
+    assert rel(vals, case["K"]) <= TOL, rel(vals, case["K"])
+    assert rel(b, case["b"]) <= TOL, rel(b, case["b"])
+    plan2, vals2, b2 = gpu_assemble(env, case)                      # bitwise reproducible
+    assert np.array_equal(vals, vals2) and np.array_equal(b, b2)
+    plan.close(); plan2.close()
+
+
+@pytest.mark.parametrize("sgfem,base,dirichlet", [(1, 416, True), (0, 408, True), (1, 408, False), (0, 416, False)])
+def test_box_level_partial_enrichment_gfem_and_64bit_flags(env, sgfem, base, dirichlet):
+    for dims, n_enr, seed in (((6, 5, 5), 1, 3), ((5, 4, 4), 2, 11), ((4, 5, 4), 3, 5)):
+        case = make_case(env, dims, n_enr, perturb=False, graded=True, vary="element", sgfem=sgfem, base=base,
+                         partial=True, dirichlet=dirichlet, seed=seed)
+        plan, vals, b = gpu_assemble(env, case)
+        assert plan.fast_path() == 2
+        assert rel(vals, case["K"]) <= TOL and rel(b, case["b"]) <= TOL
+        plan.close()
+
+
+def test_box_level_falls_back_when_a_premise_fails(env):
+    """per-Gauss-point material on a uniform mesh, and one material per element on a perturbed mesh: the general form,
+    and the plan stays there"""
+    for kw in (dict(perturb=False, vary=True), dict(perturb=True, vary="element")):
+        case = make_case(env, (6, 5, 7), 1, **kw)
+        plan, vals, b = gpu_assemble(env, case)
+        assert plan.fast_path() == 0
+        assert rel(vals, case["K"]) <= TOL and rel(b, case["b"]) <= TOL
+        plan.close()
+
+
+@pytest.mark.parametrize("nslab", [2, 3])
+def test_box_level_slabs_plus_interface_equal_the_global_system(env, nslab):
+    torch, F, dev, slab = env["torch"], env["F"], env["dev"], env["slab"]
+    case = make_case(env, (5, 4, 9), 1, perturb=False, graded=True, vary="element", partial=True)
+    M, N, P = case["dims"]
+    D, stride = case["D"], case["stride"]
+    plane_e = (M - 1) * (N - 1)
+    ranges = slab.slab_ranges(P, nslab)
+    outs, bufs, plans = [], [], []
+    for (ks, ke) in ranges:
+        cks, cke = max(ks - 1, 0), min(ke + 1, P)
+        els, ele = slab.element_range(ks, ke)
+        co = torch.from_numpy(case["coords"].reshape(P, -1)[cks:cke].reshape(-1).copy()).to(dev)
+        plan = F.Plan(F.ELASTIC3D_ENRICHED, M, N, P, coords=co, ks=ks, ke=ke, cks=cks, cke=cke, n_enr=1)
+        mat = torch.from_numpy(case["props"].reshape(-1, plane_e * stride)[els:ele].reshape(-1).copy()).to(dev)
+        vals = torch.full((plan.nnz,), float("nan"), dtype=torch.float64, device=dev)
+        b = torch.full((plan.nrows,), float("nan"), dtype=torch.float64, device=dev)
+        (_, sc), (_, rc) = plan.interface_buffers()
+        send = torch.full((max(sc, 1),), float("nan"), dtype=torch.float64, device=dev)
+        recv = torch.full((max(rc, 1),), float("nan"), dtype=torch.float64, device=dev)
+        plan.interface_set_buffers(send if sc else None, recv if rc else None)
+        plan.assemble_system(vals, b, material=mat, stride=stride, bc=F.BC_S3_ALLFACES_EXACT, e_ks=els)
+        assert plan.fast_path() == 2
+        plans.append(plan); outs.append((vals, b)); bufs.append((send, recv, sc, rc))
+    for r in range(nslab - 1):
+        bufs[r][1][:bufs[r][3]].copy_(bufs[r + 1][0][:bufs[r + 1][2]])
+    for r in range(nslab):
+        plans[r].interface_apply(outs[r][0], outs[r][1], bc=F.BC_S3_ALLFACES_EXACT)
+        plans[r].close()
+    K = np.concatenate([o[0].cpu().numpy() for o in outs])
+    b = np.concatenate([o[1].cpu().numpy() for o in outs])
+    assert not np.isnan(K).any() and not np.isnan(b).any()
+    assert rel(K, case["K"]) <= TOL and rel(b, case["b"]) <= TOL
 
 
 @pytest.mark.parametrize("perturb", [False, True])
