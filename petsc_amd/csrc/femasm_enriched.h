@@ -925,17 +925,19 @@ __global__ __launch_bounds__((64 * EnrBoxCfg<S>::NW)) void k_enr_box(const Slab 
 #pragma unroll
           for (int t = 0; t < S; t++) {
             double *wv = av[sa][t];
-            const bool on = t == 0 || (t - 1) < actp;  // an inactive family of column node b is zero on this element
+            // an inactive family of column node b is zero on this element: zero coefficients (the sums are finite)
+            const bool on = t == 0 || (t - 1) < actp;
+            const double k11 = on ? c11 : 0.0, k12 = on ? c12 : 0.0, k44 = on ? c44 : 0.0;
             const double d0 = wv[0], d1 = wv[4], d2 = wv[8];
-            wv[0] = on ? fma(c11, d0, c44 * (d1 + d2)) : 0.0;
-            wv[4] = on ? fma(c11, d1, c44 * (d0 + d2)) : 0.0;
-            wv[8] = on ? fma(c11, d2, c44 * (d0 + d1)) : 0.0;
+            wv[0] = fma(k11, d0, k44 * (d1 + d2));
+            wv[4] = fma(k11, d1, k44 * (d0 + d2));
+            wv[8] = fma(k11, d2, k44 * (d0 + d1));
 #pragma unroll
             for (int pr = 0; pr < 3; pr++) {
               const int ij = pr == 0 ? 1 : (pr == 1 ? 2 : 5), ji = pr == 0 ? 3 : (pr == 1 ? 6 : 7);
               const double wij = wv[ij], wji = wv[ji];
-              wv[ij] = on ? fma(c12, wij, c44 * wji) : 0.0;
-              wv[ji] = on ? fma(c12, wji, c44 * wij) : 0.0;
+              wv[ij] = fma(k12, wij, k44 * wji);
+              wv[ji] = fma(k12, wji, k44 * wij);
             }
           }
         // ---- phase 3: the lanes of a neighbour meet in registers along x and y, in LDS along z ----
