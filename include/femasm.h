@@ -151,8 +151,9 @@ int femasm_plan_set_stream(femasm_plan *plan, void *stream);
  *   level 0  general isoparametric elements, (E,nu) per Gauss point
  * The premise is tested exactly on every node / element touched (bitwise-equal coordinates, edge
  * vectors and material); on any failure femasm_assemble_system reassembles K one level down
- * (Poisson 2 -> 1 -> 0, elastic 2 -> 0) and the plan stays there.  Default 2.  Results of the
- * levels differ by rounding only. */
+ * (Poisson 2 -> 1 -> 0, elastic 2 -> 1 -> 0: level 1 = any hexahedra with one (E, nu) per element; enriched
+ * kind 2 -> 0: level 2 = rectilinear mesh with one (E, nu) per element) and the plan stays there.  Default 2.
+ * Results of the levels differ by rounding only. */
 int femasm_plan_set_fast_path(femasm_plan *plan, int level);
 int femasm_plan_get_fast_path(femasm_plan *plan, int *level);
 /* No counterpart in the reference.  FEMASM_ELASTIC3D_ENRICHED: how the enriched blocks are assembled.
