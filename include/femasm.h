@@ -147,7 +147,8 @@ int femasm_plan_set_stream(femasm_plan *plan, void *stream);
  *   level 2  rectilinear mesh (x depends on i only, y on j, z on k: what DMDASetUniformCoordinates
  *            P3:663 / E2:577 / S3:1198 produces; every element an axis-aligned box) with one
  *            (E,nu) per element
- *   level 1  Poisson: affine elements (parallelepipeds); elastic: as level 0
+ *   level 1  Poisson: affine elements (parallelepipeds); elastic (S3/R3): any hexahedra with one (E,nu) per
+ *            element (the material leaves the Gauss-point loop); plane strain and the enriched kind: as level 0
  *   level 0  general isoparametric elements, (E,nu) per Gauss point
  * The premise is tested exactly on every node / element touched (bitwise-equal coordinates, edge
  * vectors and material); on any failure femasm_assemble_system reassembles K one level down
