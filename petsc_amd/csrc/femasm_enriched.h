@@ -431,7 +431,7 @@ __global__ __launch_bounds__(64 * ENR_GW) void k_enr_gather(const Slab s, const 
 template <int S> struct EnrNodeCfg {
   static constexpr int NE = S - 1, D = 3 * S;
   static constexpr int SB = (S <= 2) ? S : 1;          // row families per contraction pass (9 S SB accumulators)
-  static constexpr bool ALIAS = (SB == S);             // stage + block reuse the T/U area (single pass only)
+  static constexpr bool ALIAS = (SB == S);             // the node's block reuses the T/U area (single pass only)
   static constexpr int UW = 3 + 4 * NE + 3 * S;        // coefficients, (phi, grad phi) per family, row gradients
   static constexpr int UWP = (UW + 1) & ~1;
   static constexpr int TPS = 25, TES = 8 * TPS;        // T: 25 doubles per Gauss point (24 gradients + the activity flag
@@ -440,19 +440,18 @@ template <int S> struct EnrNodeCfg {
                                                        // both when lanes (e, p) write and when lanes (e, b) read
   static constexpr int UES = 8 * UWP + 2;
   static constexpr int IN = 8 * TES + 8 * UES;
-  static constexpr int STG = 64 * 9 * S, ACC = 27 * D * D;
+  static constexpr int STG = 0, ACC = 27 * D * D;      // (no stage since round 3: the lanes of a neighbour meet in registers)
   static constexpr int OUT = (STG + ACC + 1) & ~1;
   static constexpr int PER_WAVE = ALIAS ? (IN > OUT ? IN : OUT) : IN + OUT;
   static constexpr int NW = (S <= 2) ? 8 : 2;          // waves per workgroup (LDS: 20 KB per wave for S = 2)
   static constexpr int NPW = 8;                        // consecutive nodes per wave
-  static constexpr int NV = 72 * S, NIT = (NV + 63) / 64;  // values of one element and row family, rounds of 64 lanes
 };
 
 template <int S>
 __global__ __launch_bounds__(64 * EnrNodeCfg<S>::NW) void k_enr_node(const Slab s, const EnrArgs a) {
   using Cf = EnrNodeCfg<S>;
   constexpr int NE = Cf::NE, D = Cf::D, NW = Cf::NW, SB = Cf::SB, TES = Cf::TES, TPS = Cf::TPS, UES = Cf::UES, UWP = Cf::UWP;
-  constexpr int NIT = Cf::NIT, NV = Cf::NV, RO = 3 + 4 * NE;  // RO: row gradients inside a U record
+  constexpr int RO = 3 + 4 * NE;  // RO: row gradients inside a U record
   __shared__ __attribute__((aligned(16))) double sh_w[NW][Cf::PER_WAVE];
   __shared__ double sh_G[8][3][8], sh_N[8][8];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -469,20 +468,13 @@ __global__ __launch_bounds__(64 * EnrNodeCfg<S>::NW) void k_enr_node(const Slab 
   };
   const int64_t M = s.dim[0], N = s.dim[1], P = s.dim[2];
   const int64_t mx = M - 1, my = N - 1;
-  const int e = lane >> 3, b = lane & 7;  // phase 1: Gauss point p = b
+  // lane = (element e of the 8 around the node, column node b); phase 1: Gauss point p = b.  Two bits per axis, (element
+  // side, node side) = f >> 1, f & 1: the two lanes that meet in the neighbour at offset 0 of an axis are f = 1 and f = 2 of
+  // that field -- one quad permute along x, one row shift along y (phase 3, as in k_enr_box)
+  const int fx = lane & 3, fy = (lane >> 2) & 3, fz = lane >> 4;
+  const int e = (fx >> 1) + 2 * (fy >> 1) + 4 * (fz >> 1), b = hex_idx(fx & 1, fy & 1, fz & 1);
   const int ox = (e & 1) - 1, oy = ((e >> 1) & 1) - 1, oz = (e >> 2) - 1;
   const int arow = 4 * (-oz) + ((-ox) == 0 ? ((-oy) == 0 ? 0 : 1) : ((-oy) == 0 ? 3 : 2));  // hex_idx(-ox, -oy, -oz)
-  // node-independent decode of the reduction rounds: position u = lane + 64 it of an element's 8 x 9 S staged values
-  int rd_r[NIT], rd_tc[NIT], rd_bI[NIT], rd_bJ[NIT], rd_bK[NIT];
-#pragma unroll
-  for (int it = 0; it < NIT; it++) {
-    const int u = lane + 64 * it, ub = (u < NV ? u : 0) / (9 * S), v = (u < NV ? u : 0) - 9 * S * ub;
-    rd_r[it] = v / (3 * S);
-    rd_tc[it] = v - 3 * S * rd_r[it];
-    rd_bI[it] = (ub >> 1) & 1;
-    rd_bJ[it] = ((ub + 1) >> 1) & 1;
-    rd_bK[it] = ub >> 2;
-  }
   const int64_t nn = M * N * (a.s1 - a.s0);
   const int64_t q0 = ((int64_t)blockIdx.x * NW + w) * Cf::NPW;
 #pragma unroll 1
@@ -594,11 +586,6 @@ __global__ __launch_bounds__(64 * EnrNodeCfg<S>::NW) void k_enr_node(const Slab 
       for (int t = lane; t < nvals; t += 64) acc[t] = 0.0;
     }
     if (!dirichlet) {
-      // lane-side part of the deposit position: (column node of the staged value) x D + column dof + row x rowlen
-      int rd_pos[NIT];
-#pragma unroll
-      for (int it = 0; it < NIT; it++)
-        rd_pos[it] = rd_r[it] * rowlen + ((rd_bK[it] * cnty + rd_bJ[it]) * cntx + rd_bI[it]) * D + rd_tc[it];
 #pragma unroll 1
       for (int s0 = 0; s0 < S; s0 += SB) {
         // ---- phase 2: lane (e, b), row families [s0, s0 + SB) ----
@@ -647,9 +634,13 @@ __global__ __launch_bounds__(64 * EnrNodeCfg<S>::NW) void k_enr_node(const Slab 
             for (int t = 0; t < S; t++) add_block<KIND_ELASTIC, 3>(av[sa][t], l, mm, qq, G[t]);
           }
         }
-        // ---- phase 3: stage, then the eight ordered rounds ----
-        wave_sync();  // every lane is done with T and U (which the stage may alias)
-#if FEMASM_EXP == 12 || FEMASM_EXP == 14  // profiling build: no staging, no rounds
+        // ---- phase 3 (round 3): the lanes whose blocks belong to one neighbour meet in registers along x and y (the
+        // partner's block through a quad permute / a row shift, added with a 0 / 1 factor so that every lane runs the same
+        // code; a fixed tree: deterministic) and in LDS along z (the lanes below the node write, then the lanes above it add
+        // in place: LDS executes a wave's accesses in order).  Every stored slot of the node's block has exactly one writing
+        // lane: the block is not zeroed and nothing is staged.  (Rounds 1-2: stage + eight ordered rounds, 4 of 14.6 ms.)
+        wave_sync();  // every lane is done with T and U (which the block may alias)
+#if FEMASM_EXP == 12 || FEMASM_EXP == 14  // profiling build: no sums, no deposit
 #pragma unroll
         for (int sa = 0; sa < SB; sa++)
 #pragma unroll
@@ -658,36 +649,37 @@ __global__ __launch_bounds__(64 * EnrNodeCfg<S>::NW) void k_enr_node(const Slab 
             for (int v = 0; v < 9; v++) asm volatile("" ::"v"(av[sa][t][v]));
         continue;
 #endif
-        if (Cf::ALIAS) {
-          for (int t = lane; t < nvals; t += 64) acc[t] = 0.0;
-        }
+        const double mxs = (fx == 1) ? 1.0 : 0.0, mys = (fy == 1) ? 1.0 : 0.0;
 #pragma unroll
-        for (int sa = 0; sa < SB; sa++) {
-          if (sa > 0) wave_sync();  // the rounds of the previous family have read the stage
+        for (int sa = 0; sa < SB; sa++)
 #pragma unroll
-          for (int r = 0; r < 3; r++)
+          for (int t = 0; t < S; t++)
 #pragma unroll
-            for (int t = 0; t < S; t++)
-#pragma unroll
-              for (int c = 0; c < 3; c++) stg[lane * (9 * S) + r * (3 * S) + 3 * t + c] = av[sa][t][3 * r + c];
-          wave_sync();
-          const int rowbase = 3 * (s0 + sa) * rowlen;
-#pragma unroll
-          for (int e8 = 0; e8 < 8; e8++) {
-            const int x8 = (e8 & 1) - 1, y8 = ((e8 >> 1) & 1) - 1, z8 = (e8 >> 2) - 1;
-            const int64_t fx = i + x8, fy = j + y8, fz = k + z8;
-            if (fx < 0 || fx >= mx || fy < 0 || fy >= my || fz < s.els || fz >= s.ele) continue;  // (wave-uniform)
-            const int epart = (((z8 + 1 - zi0) * cnty + (y8 + 1 - yi0)) * cntx + (x8 + 1 - xi0)) * D + rowbase;
-#pragma unroll
-            for (int it = 0; it < NIT; it++) {
-              const int u = lane + 64 * it;
-              if (u < NV) {
-                const int pos = epart + rd_pos[it];
-                acc[pos] = acc[pos] + stg[e8 * NV + u];
-              }
+            for (int v = 0; v < 9; v++) {
+              double &wv = av[sa][t][v];
+              wv = fma(mxs, quad_perm<0xD8>(wv), wv);   // fx = 1 takes fx = 2's
+              wv = fma(mys, quad_perm<0x104>(wv), wv);  // row_shl:4 -- fy = 1 takes fy = 2's
             }
-            wave_sync();  // the next element's read-modify-writes come after these
+        const int nbx = ox + (fx & 1), nby = oy + (fy & 1), nbz = oz + (fz & 1);  // the neighbour, offsets -1 .. 1
+        const bool exists = i + nbx >= 0 && i + nbx < M && j + nby >= 0 && j + nby < N && k + nbz >= 0 && k + nbz < P;
+        const bool hold = exists && fx != 2 && fy != 2;
+        const int nbpos = (((nbz + 1 - zi0) * cnty + (nby + 1 - yi0)) * cntx + (nbx + 1 - xi0)) * D;
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+          if (hold && ((fz == 2) == (pass == 1))) {
+#pragma unroll
+            for (int sa = 0; sa < SB; sa++)
+#pragma unroll
+              for (int r = 0; r < 3; r++) {
+                double *d = acc + (3 * (s0 + sa) + r) * rowlen + nbpos;
+#pragma unroll
+                for (int t = 0; t < S; t++)
+#pragma unroll
+                  for (int c = 0; c < 3; c++)
+                    d[3 * t + c] = pass ? d[3 * t + c] + av[sa][t][3 * r + c] : av[sa][t][3 * r + c];
+              }
           }
+          wave_sync();
         }
       }
     } else if (Cf::ALIAS) {
