@@ -447,7 +447,7 @@ template <int S> struct EnrNodeCfg {
   static constexpr int NPW = 8;                        // consecutive nodes per wave
 };
 
-template <int S>
+template <int S, bool ONEMAT>
 __global__ __launch_bounds__(64 * EnrNodeCfg<S>::NW) void k_enr_node(const Slab s, const EnrArgs a) {
   using Cf = EnrNodeCfg<S>;
   constexpr int NE = Cf::NE, D = Cf::D, NW = Cf::NW, SB = Cf::SB, TES = Cf::TES, TPS = Cf::TPS, UES = Cf::UES, UWP = Cf::UWP;
@@ -540,7 +540,14 @@ __global__ __launch_bounds__(64 * EnrNodeCfg<S>::NW) void k_enr_node(const Slab 
         }
       double *Up = U + e * UES + p * UWP;
       double d11 = 0.0, d12 = 0.0, d44 = 0.0;
-      if (ok) scaled_coefs<KIND_ELASTIC>(Ep, nup, wJ, d11, d12, d44);
+      if constexpr (ONEMAT) {
+        // level 1: one (E, nu) per element (every lane compares its Gauss point's pair with that of point 0; bad[1] ->
+        // the general form); the coefficients stay unscaled and w detJ goes into the row node's gradients below
+        if (ok && !(Ep == rec[96] && nup == rec[104]) && !a.iface) atomicAdd(a.bad + 1, 1ULL);
+        scaled_coefs<KIND_ELASTIC>(Ep, nup, 1.0, d11, d12, d44);
+      } else {
+        if (ok) scaled_coefs<KIND_ELASTIC>(Ep, nup, wJ, d11, d12, d44);
+      }
       Up[0] = d11;
       Up[1] = d12;
       Up[2] = d44;
@@ -563,9 +570,10 @@ __global__ __launch_bounds__(64 * EnrNodeCfg<S>::NW) void k_enr_node(const Slab 
       }
       wave_sync();  // T and the activity flags of all eight nodes of the element are in LDS
       const double g0 = Tp[3 * arow], g1 = Tp[3 * arow + 1], g2 = Tp[3 * arow + 2];
-      Up[RO] = g0;
-      Up[RO + 1] = g1;
-      Up[RO + 2] = g2;
+      const double wz = ONEMAT ? (ok ? wJ : 0.0) : 1.0;  // (level 0: w detJ is in the coefficients)
+      Up[RO] = wz * g0;
+      Up[RO + 1] = wz * g1;
+      Up[RO + 2] = wz * g2;
       if constexpr (NE > 0) {
         const int actr = *act_of(e, arow);
         const double Nr = sh_N[p][arow];
@@ -573,9 +581,9 @@ __global__ __launch_bounds__(64 * EnrNodeCfg<S>::NW) void k_enr_node(const Slab 
         for (int m = 0; m < NE; m++) {
           const double phi = Up[3 + 4 * m];
           const bool on = m < actr;
-          Up[RO + 3 * (1 + m)] = on ? phi * g0 + Nr * Up[4 + 4 * m] : 0.0;
-          Up[RO + 3 * (1 + m) + 1] = on ? phi * g1 + Nr * Up[5 + 4 * m] : 0.0;
-          Up[RO + 3 * (1 + m) + 2] = on ? phi * g2 + Nr * Up[6 + 4 * m] : 0.0;
+          Up[RO + 3 * (1 + m)] = on ? wz * (phi * g0 + Nr * Up[4 + 4 * m]) : 0.0;
+          Up[RO + 3 * (1 + m) + 1] = on ? wz * (phi * g1 + Nr * Up[5 + 4 * m]) : 0.0;
+          Up[RO + 3 * (1 + m) + 2] = on ? wz * (phi * g2 + Nr * Up[6 + 4 * m]) : 0.0;
         }
       }
     }
@@ -623,16 +631,49 @@ __global__ __launch_bounds__(64 * EnrNodeCfg<S>::NW) void k_enr_node(const Slab 
 #pragma unroll
           for (int sa = 0; sa < SB; sa++) {
             const double *R = Up + RO + 3 * (s0 + sa);
-            double l[3], mm[3], qq[3];
+            if constexpr (ONEMAT) {
+              // W^{st}[i][j] += (w detJ d_i Phi_{a,s}) d_j Phi_{b,t}: 9 FMAs per block and point
+              const double l0 = R[0], l1 = R[1], l2 = R[2];
 #pragma unroll
-            for (int kk = 0; kk < 3; kk++) {
-              l[kk] = d12 * R[kk];
-              mm[kk] = d44 * R[kk];
-              qq[kk] = d11 * R[kk];
+              for (int t = 0; t < S; t++) {
+                double *wv = av[sa][t];
+                wv[0] = fma(l0, G[t][0], wv[0]); wv[1] = fma(l0, G[t][1], wv[1]); wv[2] = fma(l0, G[t][2], wv[2]);
+                wv[3] = fma(l1, G[t][0], wv[3]); wv[4] = fma(l1, G[t][1], wv[4]); wv[5] = fma(l1, G[t][2], wv[5]);
+                wv[6] = fma(l2, G[t][0], wv[6]); wv[7] = fma(l2, G[t][1], wv[7]); wv[8] = fma(l2, G[t][2], wv[8]);
+              }
+            } else {
+              double l[3], mm[3], qq[3];
+#pragma unroll
+              for (int kk = 0; kk < 3; kk++) {
+                l[kk] = d12 * R[kk];
+                mm[kk] = d44 * R[kk];
+                qq[kk] = d11 * R[kk];
+              }
+#pragma unroll
+              for (int t = 0; t < S; t++) add_block<KIND_ELASTIC, 3>(av[sa][t], l, mm, qq, G[t]);
             }
-#pragma unroll
-            for (int t = 0; t < S; t++) add_block<KIND_ELASTIC, 3>(av[sa][t], l, mm, qq, G[t]);
           }
+        }
+        if constexpr (ONEMAT) {
+          // the material, once per block: K[i][j] = c12 W[i][j] + c44 W[j][i], K[i][i] = c11 W[i][i] + c44 (W[j][j] + W[k][k])
+          const double c11 = U[e * UES], c12 = U[e * UES + 1], c44 = U[e * UES + 2];
+#pragma unroll
+          for (int sa = 0; sa < SB; sa++)
+#pragma unroll
+            for (int t = 0; t < S; t++) {
+              double *wv = av[sa][t];
+              const double w0 = wv[0], w1 = wv[4], w2 = wv[8];
+              wv[0] = fma(c11, w0, c44 * (w1 + w2));
+              wv[4] = fma(c11, w1, c44 * (w0 + w2));
+              wv[8] = fma(c11, w2, c44 * (w0 + w1));
+#pragma unroll
+              for (int pr = 0; pr < 3; pr++) {
+                const int ij = pr == 0 ? 1 : (pr == 1 ? 2 : 5), ji = pr == 0 ? 3 : (pr == 1 ? 6 : 7);
+                const double wij = wv[ij], wji = wv[ji];
+                wv[ij] = fma(c12, wij, c44 * wji);
+                wv[ji] = fma(c12, wji, c44 * wij);
+              }
+            }
         }
         // ---- phase 3 (round 3): the lanes whose blocks belong to one neighbour meet in registers along x and y (the
         // partner's block through a quad permute / a row shift, added with a 0 / 1 factor so that every lane runs the same

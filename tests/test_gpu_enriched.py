@@ -73,13 +73,16 @@ def make_case(env, dims, n_enr, perturb=True, sgfem=1, base=408, partial=False, 
                 sgfem=sgfem, dirichlet=dirichlet, D=D)
 
 
-def gpu_assemble(env, case, mode=-1, ks=0, ke=None, options=None):
+def gpu_assemble(env, case, mode=-1, ks=0, ke=None, options=None, level=None, plan=None):
     torch, F, dev = env["torch"], env["F"], env["dev"]
     M, N, P = case["dims"]
-    plan = F.Plan(F.ELASTIC3D_ENRICHED, M, N, P, coords=torch.from_numpy(case["coords"]).to(dev), n_enr=case["n_enr"],
-                  options=options)
+    if plan is None:
+        plan = F.Plan(F.ELASTIC3D_ENRICHED, M, N, P, coords=torch.from_numpy(case["coords"]).to(dev),
+                      n_enr=case["n_enr"], options=options)
     if mode >= 0:
         plan.set_enriched_contraction(mode)
+    if level is not None:
+        plan.set_fast_path(level)
     assert plan.dof == case["D"] or True
     vals = torch.full((plan.nnz,), float("nan"), dtype=torch.float64, device=dev)
     b = torch.full((plan.nrows,), float("nan"), dtype=torch.float64, device=dev)
@@ -148,15 +151,47 @@ def test_box_level_partial_enrichment_gfem_and_64bit_flags(env, sgfem, base, dir
         plan.close()
 
 
-def test_box_level_falls_back_when_a_premise_fails(env):
-    """per-Gauss-point material on a uniform mesh, and one material per element on a perturbed mesh: the general form,
-    and the plan stays there"""
-    for kw in (dict(perturb=False, vary=True), dict(perturb=True, vary="element")):
+def test_levels_fall_back_when_a_premise_fails(env):
+    """per-Gauss-point material on a uniform mesh: the material premise fails, which level 1 shares -> level 0 at once;
+    one material per element on a perturbed mesh: level 1 (general hexahedra, material outside the Gauss-point loop);
+    per-Gauss-point material on a perturbed mesh: level 2 -> 1 -> 0.  The plan stays where it lands."""
+    for kw, want in ((dict(perturb=False, vary=True), 0), (dict(perturb=True, vary="element"), 1),
+                     (dict(perturb=True, vary=True), 0)):
         case = make_case(env, (6, 5, 7), 1, **kw)
         plan, vals, b = gpu_assemble(env, case)
-        assert plan.fast_path() == 0
+        assert plan.fast_path() == want
+        assert rel(vals, case["K"]) <= TOL and rel(b, case["b"]) <= TOL
+        _, vals2, b2 = gpu_assemble(env, case, plan=plan)
+        assert plan.fast_path() == want
+        assert np.array_equal(vals2, vals) and np.array_equal(b2, b)
+        plan.close()
+
+
+@pytest.mark.parametrize("n_enr", [0, 1, 2, 3])
+def test_level_1_general_hexahedra_one_material_per_element(env, n_enr):
+    """k_enr_node<S, one material>: perturbed mesh, (E, nu) constant per element and different between elements,
+    partially enriched elements, both enrichment modes"""
+    for sgfem in ((1, 0) if n_enr else (1,)):
+        case = make_case(env, (5, 6, 4), n_enr, perturb=True, vary="element", partial=n_enr > 0, sgfem=sgfem)
+        plan, vals, b = gpu_assemble(env, case)
+        assert plan.fast_path() == 1
         assert rel(vals, case["K"]) <= TOL and rel(b, case["b"]) <= TOL
         plan.close()
+
+
+def test_level_1_started_there_and_level_0_forced(env):
+    """set_fast_path(1) skips the box attempt; set_fast_path(0) gives the general form on a mesh both levels would take"""
+    case = make_case(env, (6, 4, 5), 1, perturb=True, vary="element", partial=True)
+    for start, want in ((1, 1), (0, 0)):
+        plan, vals, b = gpu_assemble(env, case, level=start)
+        assert plan.fast_path() == want
+        assert rel(vals, case["K"]) <= TOL and rel(b, case["b"]) <= TOL
+        plan.close()
+    case = make_case(env, (6, 4, 5), 1, perturb=True, vary=True)
+    plan, vals, b = gpu_assemble(env, case, level=1)
+    assert plan.fast_path() == 0
+    assert rel(vals, case["K"]) <= TOL and rel(b, case["b"]) <= TOL
+    plan.close()
 
 
 @pytest.mark.parametrize("nslab", [2, 3])
