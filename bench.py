@@ -253,12 +253,14 @@ HEX_FLOPS_PER_ELEMENT = 8 * (2 * 72 + 60 + 2 * 72 + 96 + 64 * 2 * 9 + 24) + 64 *
 def kernel_name(wl, level, args):
     if wl == "enriched3d":
         mode = args.enr_contraction if args.enr_contraction != "default" else "node"
-        return ((f"k_enr_box<S={1 + args.n_enr}>" if level == 2 else f"k_enr_node<S={1 + args.n_enr}>") if mode == "node" else
+        return ((f"k_enr_box<S={1 + args.n_enr}>" if level == 2 else
+                 f"k_enr_node<S={1 + args.n_enr},{'one material per element' if level == 1 else 'general'}>")
+                if mode == "node" else
                 f"k_enr_elem<S={1 + args.n_enr},{mode}> + k_enr_gather (all of K)")
     if wl == "elastic2d":
         return "k_assemble_e2_rect" if level == 2 else "k_assemble_ke_e2"
     if wl == "poisson3d":
-        return {2: "k_assemble_p3_rect", 1: "k_assemble_rowsweep<POISSON3D>"}.get(level, "k_assemble_ke_p3")
+        return {2: "k_assemble_p3_rect", 1: "k_assemble_rowsweep<POISSON3D>"}.get(level, "k_assemble_p3_hex")
     return {2: "k_assemble_s3_unit", 1: "k_assemble_s3_hex2"}.get(level, "k_assemble_sweep<ELASTIC3D>")
 
 

@@ -147,13 +147,13 @@ int femasm_plan_set_stream(femasm_plan *plan, void *stream);
  *   level 2  rectilinear mesh (x depends on i only, y on j, z on k: what DMDASetUniformCoordinates
  *            P3:663 / E2:577 / S3:1198 produces; every element an axis-aligned box) with one
  *            (E,nu) per element
- *   level 1  Poisson: affine elements (parallelepipeds); elastic (S3/R3): any hexahedra with one (E,nu) per
- *            element (the material leaves the Gauss-point loop); plane strain and the enriched kind: as level 0
+ *   level 1  Poisson: affine elements (parallelepipeds); elastic (S3/R3) and the enriched kind: any hexahedra with
+ *            one (E,nu) per element (the material leaves the Gauss-point loop); plane strain: as level 0
  *   level 0  general isoparametric elements, (E,nu) per Gauss point
  * The premise is tested exactly on every node / element touched (bitwise-equal coordinates, edge
  * vectors and material); on any failure femasm_assemble_system reassembles K one level down
- * (Poisson 2 -> 1 -> 0, elastic 2 -> 1 -> 0: level 1 = any hexahedra with one (E, nu) per element; enriched
- * kind 2 -> 0: level 2 = rectilinear mesh with one (E, nu) per element) and the plan stays there.  Default 2.
+ * (Poisson 2 -> 1 -> 0; elastic and enriched 2 -> 1 -> 0, and 2 -> 0 at once when the failed premise is the
+ * material's, which level 1 shares) and the plan stays there.  Default 2.
  * Results of the levels differ by rounding only. */
 int femasm_plan_set_fast_path(femasm_plan *plan, int level);
 int femasm_plan_get_fast_path(femasm_plan *plan, int *level);
@@ -175,7 +175,8 @@ int femasm_plan_set_enriched_contraction(femasm_plan *plan, int mode);
  *   "rhs_grid"        cap on the resident grid of the S3 right-hand-side pass
  *   "enr_scratch_mb"  enriched kind, two-kernel form: size of the element-matrix ring
  *   "s3_rowsweep"     1: elastic boxes through k_assemble_rowsweep<ELASTIC> instead of k_assemble_s3_unit
- *   "p3_sweep"        1: Poisson on general hexahedra through the node-row kernel instead of k_assemble_ke_p3
+ *   "p3_sweep"        Poisson on general hexahedra: 1 the node-row kernel, 2 the element-matrix kernel of round 2
+ *                     (k_assemble_ke_p3) instead of k_assemble_p3_hex (element matrices in tensor-product form)
  *   "e2_brick"        1: plane strain on general quadrilaterals through the brick kernel for every row
  *   "e2_two_pass"     1: plane strain on boxes, K and b in two passes
  *   "enr_rhs_simple"  1: enriched kind, the per-element right-hand side

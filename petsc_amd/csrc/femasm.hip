@@ -8,6 +8,7 @@
 #include "femasm_kernels.h"
 #include "femasm_sweep.h"
 #include "femasm_hex2.h"
+#include "femasm_p3hex.h"
 #include "femasm_enriched.h"
 
 #include <hipcub/hipcub.hpp>
@@ -228,7 +229,7 @@ struct femasm_plan {
     int64_t rhs_grid = 0;        // cap on the resident grid of the S3 RHS pass
     int64_t enr_scratch_mb = 0;  // enriched kind, two-kernel form: ring size
     int s3_rowsweep = 0;         // elastic boxes: k_assemble_rowsweep<ELASTIC> instead of k_assemble_s3_unit
-    int p3_sweep = 0;            // P3 general: k_assemble_sweep_p3 instead of k_assemble_ke_p3
+    int p3_sweep = 0;            // P3 general: 1 = k_assemble_sweep_p3 (round 1), 2 = k_assemble_ke_p3 (round 2) instead of k_assemble_p3_hex
     int e2_brick = 0;            // E2 general: the brick kernel for every row instead of k_assemble_ke_e2
     int e2_two_pass = 0;         // E2 boxes: K and b in two passes
     int enr_rhs_simple = 0;      // enriched kind: the per-element RHS
@@ -517,8 +518,30 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
       } else {
         dim3 grid((unsigned)((b.x1 - b.x0 + SW_TX - 1) / SW_TX), (unsigned)((b.y1 - b.y0 + SW_TY - 1) / SW_TY),
                   (unsigned)((z1 - z0 + SW_ZC - 1) / SW_ZC));
-        if (KIND == KIND_POISSON && !p->opt.p3_sweep) {
-          // element matrices through LDS (FEMASM_P3_SWEEP=1: the node-row kernel of round 1, for A/B)
+        if (KIND == KIND_POISSON && !p->opt.p3_sweep && 3 * M * N < ((int64_t)1 << 31)) {
+          // element matrices in tensor-product form, through LDS (femasm_p3hex.h; option p3_sweep = 2: the element-matrix
+          // kernel of round 2, 1: the node-row kernel of round 1, for A/B)
+          // node layers per workgroup: a chunk of zc node layers sweeps zc + 1 element layers, and the last round of the
+          // resident workgroups (two per CU: one wave per SIMD) should be full (256^3: 16 -> 1.61 ms, 32 -> 1.57 ms)
+          const int64_t tiles = ((b.x1 - b.x0 + PH_TX - 1) / PH_TX) * ((b.y1 - b.y0 + PH_TY - 1) / PH_TY);
+          const int64_t nz = z1 - z0, resident = (int64_t)p->ncu * 2;
+          int64_t zc = nz;
+          double best = -1.0;
+          for (int64_t chunks = 1; chunks <= nz; chunks++) {
+            const int64_t c = (nz + chunks - 1) / chunks, rc = (nz + c - 1) / c;
+            if (c < 8 && chunks > 1) break;
+            const int64_t W = tiles * rc, rounds = (W + resident - 1) / resident;
+            const double eff = (double)W / (double)(rounds * resident) * (double)nz / (double)(nz + rc) * (1.0 - 0.25 / (double)rounds);
+            if (eff > best + 1e-9) { best = eff; zc = c; }
+          }
+          if (p->opt.zc > 0) zc = p->opt.zc;
+          KArgs az = a;
+          az.zc = (int32_t)zc;
+          if (p->opt.debug) fprintf(stderr, "[femasm] poisson level 0: %lld tiles, %lld node layers per workgroup\n", (long long)tiles, (long long)zc);
+          dim3 gph((unsigned)((b.x1 - b.x0 + PH_TX - 1) / PH_TX), (unsigned)((b.y1 - b.y0 + PH_TY - 1) / PH_TY),
+                   (unsigned)((nz + zc - 1) / zc));
+          hipLaunchKernelGGL(k_assemble_p3_hex, gph, dim3(PH_NT), 0, p->stream, p->s, az);
+        } else if (KIND == KIND_POISSON && p->opt.p3_sweep != 1) {
           dim3 gke((unsigned)((b.x1 - b.x0 + KE_TX - 1) / KE_TX), (unsigned)((b.y1 - b.y0 + KE_TY - 1) / KE_TY),
                    (unsigned)((z1 - z0 + KE_ZC - 1) / KE_ZC));
           hipLaunchKernelGGL(k_assemble_ke_p3, gke, dim3(256), 0, p->stream, p->s, a);
@@ -704,10 +727,11 @@ void launch_enr_elem(femasm_plan *p, const EnrArgs &a, int64_t nelem, bool mfma)
 }
 
 template <int S>
-void launch_enr_node(femasm_plan *p, const EnrArgs &a, int64_t nnodes) {
+void launch_enr_node(femasm_plan *p, const EnrArgs &a, int64_t nnodes, bool onemat) {
   constexpr int per_wg = EnrNodeCfg<S>::NW * EnrNodeCfg<S>::NPW;
   const dim3 grid((unsigned)((nnodes + per_wg - 1) / per_wg));
-  hipLaunchKernelGGL((k_enr_node<S>), grid, dim3(64 * EnrNodeCfg<S>::NW), 0, p->stream, p->s, a);
+  if (onemat) hipLaunchKernelGGL((k_enr_node<S, true>), grid, dim3(64 * EnrNodeCfg<S>::NW), 0, p->stream, p->s, a);
+  else hipLaunchKernelGGL((k_enr_node<S, false>), grid, dim3(64 * EnrNodeCfg<S>::NW), 0, p->stream, p->s, a);
 }
 template <int S>
 void launch_enr_box(femasm_plan *p, const EnrArgs &a0, int64_t nnodes) {
@@ -801,7 +825,7 @@ int assemble_enriched(femasm_plan *p, const femasm_material *mat, int bc, double
     if (stats) HIPCHK(hipEventRecord(p->ev[4], p->stream));
     // default: one node-centric pass (k_enr_node), nothing but the CSR values leaves the chip; the two-kernel
     // form (element matrices through a scratch ring) is what femasm_plan_set_enriched_contraction(0 | 1) selects
-    bool box = false;
+    bool box = false, onemat = false;
     auto node_pass = [&](double *out, int64_t l0, int64_t l1, int iface) {
       if (l1 <= l0) return;
       EnrArgs g = a;
@@ -820,19 +844,23 @@ int assemble_enriched(femasm_plan *p, const femasm_material *mat, int bc, double
         }
       } else {
         switch (S) {
-          case 1: launch_enr_node<1>(p, g, nn); break;
-          case 2: launch_enr_node<2>(p, g, nn); break;
-          case 3: launch_enr_node<3>(p, g, nn); break;
-          default: launch_enr_node<4>(p, g, nn); break;
+          case 1: launch_enr_node<1>(p, g, nn, onemat); break;
+          case 2: launch_enr_node<2>(p, g, nn, onemat); break;
+          case 3: launch_enr_node<3>(p, g, nn, onemat); break;
+          default: launch_enr_node<4>(p, g, nn, onemat); break;
         }
       }
     };
     if (!two_phase) {
-      // level 2 of this kind (round 3): box elements with one material each, both premises tested on the device (the
-      // rectilinearity pre-pass and phase 1 of the kernel raise bad[1]); on a failure K is assembled again by the
-      // general form below and the plan stays there
-      for (int attempt = 0; attempt < 2; attempt++) {
-        box = p->fast_level == 2;
+      // levels of this kind (round 3).  2: box elements with one material each (k_enr_box; the rectilinearity pre-pass and
+      // phase 1 of the kernel raise bad[1], the pre-pass also bad[3]); 1: any hexahedra with one material each (k_enr_node
+      // with the material outside the Gauss-point loop; phase 1 raises bad[1]); 0: the general form.  On a failure K is
+      // assembled again one level down -- or two, when the failed premise is the material's, which level 1 shares -- and
+      // the plan stays there
+      for (int attempt = 0; attempt < 3; attempt++) {
+        const int level = p->fast_level;
+        box = level == 2;
+        onemat = level == 1;
         if (box) {
           if (int rcr = launch_rect_check(p)) return rcr;
         }
@@ -842,13 +870,14 @@ int assemble_enriched(femasm_plan *p, const femasm_material *mat, int bc, double
         }
         node_pass(csr_values, s.ks, s.ke, 0);
         HIPCHK(hipGetLastError());
-        if (!box) break;
+        if (level == 0) break;
         unsigned long long *fl = p->flags_host;
-        fl[1] = 0;
-        HIPCHK(hipMemcpyAsync(fl + 1, p->bad + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, p->stream));
+        fl[1] = fl[2] = fl[3] = 0;
+        HIPCHK(hipMemcpyAsync(fl + 1, p->bad + 1, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, p->stream));
         HIPCHK(hipStreamSynchronize(p->stream));
         if (!fl[1]) break;
-        p->fast_level = 0;  // general hexahedra or per-Gauss-point material: the general form, from now on
+        // (the pre-pass counts a non-box element in bad[1] and in bad[3]: any excess of bad[1] is the material's)
+        p->fast_level = (level == 2 && fl[1] == fl[3]) ? 1 : 0;
         HIPCHK(hipMemsetAsync(p->bad, 0, 4 * sizeof(unsigned long long), p->stream));
       }
     }
@@ -1091,6 +1120,17 @@ int femasm_plan_destroy(femasm_plan *p) {
   if (!p) return FEMASM_OK;
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
+#if PH_EXP == 9
+  {  // phase clocks of k_assemble_p3_hex (profiling build): summed over all waves and launches, per wave-step
+    unsigned long long t[32];
+    if (p->bad && hipMemcpy(t, p->bad, sizeof t, hipMemcpyDeviceToHost) == hipSuccess && t[16]) {
+      const char *nm[8] = {"coords", "B1", "element", "B2", "gather", "B3", "stage+B4", "store"};
+      fprintf(stderr, "[femasm p3hex phases] cycles per wave-step (%llu wave-steps):", t[16]);
+      for (int q = 0; q < 8; q++) fprintf(stderr, " %s %.0f |", nm[q], (double)t[8 + q] / t[16]);
+      fprintf(stderr, "\n");
+    }
+  }
+#endif
 #if H2_EXP == 9
   {  // phase clocks of k_assemble_s3_hex2 (profiling build): one workgroup, two of its waves, summed over launches
     unsigned long long t[32];
@@ -1153,7 +1193,7 @@ int femasm_plan_set_option(femasm_plan *p, const char *name, int64_t value) {
   else if (n == "rhs_grid") o.rhs_grid = value;
   else if (n == "enr_scratch_mb") o.enr_scratch_mb = value;
   else if (n == "s3_rowsweep") o.s3_rowsweep = value != 0;
-  else if (n == "p3_sweep") o.p3_sweep = value != 0;
+  else if (n == "p3_sweep") o.p3_sweep = (value == 2) ? 2 : (value != 0);
   else if (n == "e2_brick") o.e2_brick = value != 0;
   else if (n == "e2_two_pass") o.e2_two_pass = value != 0;
   else if (n == "enr_rhs_simple") o.enr_rhs_simple = value != 0;

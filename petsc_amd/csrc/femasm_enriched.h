@@ -420,10 +420,13 @@ __global__ __launch_bounds__(64 * ENR_GW) void k_enr_gather(const Slab s, const 
 //            (an element outside the mesh or outside the layers this rank assembles gets zero coefficients)
 //   phase 2  lane (e, b): column node b of element e.  All S x S blocks (row family s, column family t) of the pair
 //            (this node, b) over the eight Gauss points: 21 FMAs per block and point, accumulators in registers
-//   phase 3  per row family: registers -> stage[e][b][r][t][c] (aliases T/U, which are dead by then), then eight
-//            conflict-free rounds, one per element in the reference's ADD order, add the 8 x 9 S values of element e into
-//            the node's CSR block in LDS; row rules (Dirichlet faces, blocked redundant dofs); the block is contiguous
-//            in the CSR array and is written 16 B per lane from the 128-byte boundary below it.
+//   phase 3  per row family (round 3): lane = two bits per axis (element side, node side); the two lanes that meet in a
+//            neighbour are added in registers along x (quad permute) and y (row shift) and in LDS along z (the lanes below
+//            the node write, the lanes above add in place): a fixed tree, one writer per slot of the node's CSR block in
+//            LDS (rounds 1-2: a stage and eight ordered rounds); row rules (Dirichlet faces, blocked redundant dofs); the
+//            block is contiguous in the CSR array and is written 16 B per lane from the 128-byte boundary below it.
+//   ONEMAT   (level 1 of this kind) one (E, nu) per element, tested bitwise in phase 1 (bad[1]): the row gradients carry
+//            w detJ, phase 2 accumulates W^{st}[i][j] with 9 FMAs per block and point, the material is applied once.
 // Each element's geometry is computed by the eight waves of its nodes (8 x 64 Jacobians per node, ~20 % of the
 // arithmetic); in exchange the kernel's HBM traffic is the CSR values plus the (cached) records.
 // Every CSR value has one writer and a fixed order of additions: bitwise reproducible.

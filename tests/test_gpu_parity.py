@@ -629,17 +629,46 @@ def test_element_soa_material_on_an_upper_slab(env, mesh):
     plan.close()
 
 
-@pytest.mark.parametrize("kernel", ["ke", "sweep"])
-@pytest.mark.parametrize("dims", [(33, 9, 21), (17, 5, 4), (4, 3, 5), (47, 12, 35)])
-def test_p3_general_kernels_element_matrix_and_node_row(env, monkeypatch, kernel, dims):
-    """Poisson K on general hexahedra has two kernels: k_assemble_ke_p3 (default: the 36 unique entries of each element
-    matrix formed once, node rows gathered from LDS; 15 x 3 node tiles) and the node-row kernel k_assemble_sweep_p3
-    (option "p3_sweep").  Both against the oracle on perturbed meshes whose extents are not multiples of either tile."""
+@pytest.mark.parametrize("kernel", ["hex", "ke", "sweep"])
+@pytest.mark.parametrize("dims", [(33, 9, 21), (17, 5, 4), (4, 3, 5), (47, 12, 35), (18, 10, 3), (3, 3, 40)])
+def test_p3_general_kernels_tensor_product_element_matrix_and_node_row(env, monkeypatch, kernel, dims):
+    """Poisson K on general hexahedra has three kernels: k_assemble_p3_hex (default since round 3: the element matrix in
+    tensor-product form, 15 x 7 node tiles), k_assemble_ke_p3 (option "p3_sweep" = 2: the 36 unique entries of each
+    element matrix from literal reference gradients, 15 x 3 node tiles) and the node-row kernel k_assemble_sweep_p3
+    ("p3_sweep" = 1).  All against the oracle on perturbed meshes whose extents are not multiples of any tile."""
     case = make_case(env, "p3", dims, perturb=True)
-    plan, vals, gb = gpu_assemble(env, case, options={"p3_sweep": 1} if kernel == "sweep" else None)
+    opts = {"hex": None, "ke": {"p3_sweep": 2}, "sweep": {"p3_sweep": 1}}[kernel]
+    plan, vals, gb = gpu_assemble(env, case, options=opts)
     assert plan.fast_path() == 0
     assert not np.isnan(vals).any()
     assert rel(vals, case["K"]) <= TOL and rel(gb, case["b"]) <= TOL
+    plan.close()
+
+
+@pytest.mark.parametrize("zc", [1, 2, 5])
+def test_p3_hex_node_layers_per_workgroup(env, zc):
+    """k_assemble_p3_hex marches zc node layers per workgroup (option "zc"; the launch picks it from the mesh): chunks of
+    one, two and five layers over 11 interior layers give the same K bit for bit as the launch's own choice"""
+    case = make_case(env, "p3", (20, 11, 13), perturb=True)
+    plan0, vals0, _ = gpu_assemble(env, case)
+    plan, vals, gb = gpu_assemble(env, case, options={"zc": zc})
+    assert rel(vals, case["K"]) <= TOL and rel(gb, case["b"]) <= TOL
+    assert np.array_equal(vals, vals0)
+    plan.close(); plan0.close()
+
+
+def test_p3_hex_inverted_element_is_reported(env):
+    """det J <= 0 at a Gauss point of the Poisson kind on a distorted mesh -> FEMASM_ERR_GEOMETRY after the call"""
+    torch, F, dev, O = env["torch"], env["F"], env["dev"], env["O"]
+    M = N = P = 7
+    coords = O.perturb_coords(O.uniform_coords(3, M, N, P), 3, M, N, P).reshape(-1, 3)
+    coords[2 + M * (3 + N * 3)] = coords[4 + M * (3 + N * 3)] + np.array([0.01, 0.0, 0.0])  # pushed past its neighbour
+    plan = F.Plan(F.POISSON3D_Q1, M, N, P, coords=torch.from_numpy(coords.reshape(-1).copy()).to(dev))
+    vals = torch.empty(plan.nnz, dtype=torch.float64, device=dev)
+    b = torch.empty(plan.nrows, dtype=torch.float64, device=dev)
+    with pytest.raises(F.FemasmError) as ei:
+        plan.assemble_system(vals, b, bc=F.BC_POISSON_INLOOP)
+    assert ei.value.code == 3 and "det(J)" in str(ei.value)
     plan.close()
 
 
