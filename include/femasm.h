@@ -179,6 +179,8 @@ int femasm_plan_set_enriched_contraction(femasm_plan *plan, int mode);
  *                     (k_assemble_ke_p3) instead of k_assemble_p3_hex (element matrices in tensor-product form)
  *   "e2_brick"        1: plane strain on general quadrilaterals through the brick kernel for every row
  *   "e2_two_pass"     1: plane strain on boxes, K and b in two passes
+ *   "rhs_simple"      1: Poisson load on general hexahedra per Gauss point as the reference states it (library sinpi)
+ *                     instead of the tensor-product form
  *   "enr_rhs_simple"  1: enriched kind, the per-element right-hand side
  *   "debug"           1: launch facts on stderr
  * Results differ by rounding at most (every variant is tested against the oracle). */

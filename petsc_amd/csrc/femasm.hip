@@ -232,6 +232,7 @@ struct femasm_plan {
     int p3_sweep = 0;            // P3 general: 1 = k_assemble_sweep_p3 (round 1), 2 = k_assemble_ke_p3 (round 2) instead of k_assemble_p3_hex
     int e2_brick = 0;            // E2 general: the brick kernel for every row instead of k_assemble_ke_e2
     int e2_two_pass = 0;         // E2 boxes: K and b in two passes
+    int rhs_simple = 0;          // P3 general: the load per Gauss point as the reference states it (library sinpi)
     int enr_rhs_simple = 0;      // enriched kind: the per-element RHS
     int debug = 0;               // prints launch facts to stderr
   } opt;
@@ -633,6 +634,7 @@ int launch_rhs(femasm_plan *p, const femasm_material *mat, int bc, double *out, 
   a.E = mat ? mat->E : 0.0;
   a.nu = mat ? mat->nu : 0.0;
   a.cond = p->cond_rhs ? 1 : 0;
+  a.simple = p->opt.rhs_simple;
   // S3/R3 with the reference's AoS records as 16-byte runs: streaming element pass + in-wave part of the node sum
   // (k_rhs_elem_elastic_runs); anything else (uniform material: no loads; an odd stride or base) takes the
   // thread-per-element kernel and the element-vector form of the gather
@@ -1196,6 +1198,7 @@ int femasm_plan_set_option(femasm_plan *p, const char *name, int64_t value) {
   else if (n == "p3_sweep") o.p3_sweep = (value == 2) ? 2 : (value != 0);
   else if (n == "e2_brick") o.e2_brick = value != 0;
   else if (n == "e2_two_pass") o.e2_two_pass = value != 0;
+  else if (n == "rhs_simple") o.rhs_simple = value != 0;
   else if (n == "enr_rhs_simple") o.enr_rhs_simple = value != 0;
   else if (n == "debug") o.debug = value != 0;
   else return fail(FEMASM_ERR_ARG, "unknown option '%s'", name);

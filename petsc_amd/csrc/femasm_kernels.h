@@ -579,6 +579,31 @@ __global__ __launch_bounds__(256, 2) void k_assemble_rows(const Slab s, const KA
 // ---------------------------------------------------------------------------
 // RHS, pass 1: one thread per assembled element -> Fe (and Ge) in the scratch array
 // ---------------------------------------------------------------------------
+// sin(pi x) for the Poisson load on general hexahedra (P3:556 evaluates sin(PI * x) at every Gauss point: 24 sines per
+// element).  r = x - rint(x), |r| <= 1/2, sin(pi x) = (-1)^rint(x) sin(pi r) with ONE odd Taylor polynomial of degree 21 in
+// r (truncation 1e-18 at |r| = 1/2, coefficients rounded from 60 digits; relative error <= 4e-16 over the interval,
+// scripts/ check in DESIGN 4.5): 17 instructions where the library's sinpi (a sine and a cosine polynomial and a select,
+// any argument class) takes 40.  Inf/NaN arguments give NaN, like the library's.
+__device__ inline double sinpi_poly(double x) {
+  const double n = rint(x), r = x - n, t = r * r;
+  double p = 5.392664662608129e-10;
+  p = fma(p, t, -2.2948428997269873e-08);
+  p = fma(p, t, 7.952054001475513e-07);
+  p = fma(p, t, -2.1915353447830217e-05);
+  p = fma(p, t, 0.00046630280576761255);
+  p = fma(p, t, -0.0073704309457143504);
+  p = fma(p, t, 0.08214588661112823);
+  p = fma(p, t, -0.5992645293207921);
+  p = fma(p, t, 2.5501640398773455);
+  p = fma(p, t, -5.16771278004997);
+  p = fma(p, t, 3.141592653589793);
+  // parity of n: n is an integer-valued double; n * 0.5 has a fractional part iff n is odd (exact for |n| < 2^52; larger
+  // arguments are even integers times ulp: r = 0 and the sign does not matter)
+  const double h = n * 0.5;
+  const double sgn = (h != rint(h)) ? -r : r;
+  return p * sgn;
+}
+
 #define PH_BUF a.bad
 #if FEMASM_EXP == 3  // phase clocks (profiling build only): PH_ACC(p, id) adds the time since the last mark to phase p
 #define PH_DECL unsigned long long ph_[4] = {0, 0, 0, 0}, ph_n = 0, ph_t = __builtin_readcyclecounter()
@@ -626,6 +651,7 @@ struct RArgs {
   int32_t runs;             // elemF holds the records of k_rhs_elem_elastic_runs, not element vectors
   double E, nu;             // FEMASM_MAT_MANUFACTURED: the drivers' -iso_E / -iso_nu
   int32_t cond;             // k_rhs_e2_fused: run only if bad[1] != 0 (the one-pass kernel's premise failed: b again)
+  int32_t simple;           // option rhs_simple: the Poisson load on general hexahedra as the reference states it
 };
 
 template <int KIND>
@@ -695,18 +721,100 @@ __device__ inline void rhs_elem_one(const Slab &s, const RArgs &a, int64_t e) {
 #pragma unroll
           for (int i = 0; i < 8; i++) F[i] += fac * fv * c_tab3.N[p][i];
         }
-      } else
-      for (int p = 0; p < 8; p++) {  // P3:549-566
-        const double fac = 1.0 * det3_only(c_tab3.G[p], xc);
-        double pos[3] = {0.0, 0.0, 0.0};
+      } else if (a.simple) {
+        for (int p = 0; p < 8; p++) {  // P3:549-566, as the reference states it (option rhs_simple: for A/B and tests)
+          const double fac = 1.0 * det3_only(c_tab3.G[p], xc);
+          double pos[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-        for (int n = 0; n < 8; n++)
+          for (int n = 0; n < 8; n++)
 #pragma unroll
-          for (int d = 0; d < 3; d++) pos[d] += c_tab3.N[p][n] * xc[3 * n + d];
-        // sinpi: the reference's sin(pi*x) without the large-argument reduction (differs by ~1 ulp of the argument)
-        const double fv = 3.0 * PI * PI * sinpi(pos[0]) * sinpi(pos[1]) * sinpi(pos[2]);
+            for (int d = 0; d < 3; d++) pos[d] += c_tab3.N[p][n] * xc[3 * n + d];
+          // sinpi: the reference's sin(pi*x) without the large-argument reduction (differs by ~1 ulp of the argument)
+          const double fv = 3.0 * PI * PI * sinpi(pos[0]) * sinpi(pos[1]) * sinpi(pos[2]);
 #pragma unroll
-        for (int i = 0; i < 8; i++) F[i] += fac * fv * c_tab3.N[p][i];
+          for (int i = 0; i < 8; i++) F[i] += fac * fv * c_tab3.N[p][i];
+        }
+      } else {
+        // P3:549-566 on a general hexahedron in the tensor-product form of the trilinear map (round 3; as the geometry of
+        // k_assemble_p3_hex): x(xi) = sum c_ijk xi^i eta^j zeta^k / 8 with c the Hadamard transform of the node
+        // coordinates; every row of 8 J takes four values over the Gauss points; det J = r0 . (r1 x r2) / 512; the Gauss
+        // points' positions by three butterfly stages.  810 instead of 2 200 instructions per element (24 of the
+        // library's sinpi were 960 of them).  Same sums in a different order: rounding only.
+        double c[2][2][2][3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          double v[2][2][2];
+#pragma unroll
+          for (int n = 0; n < 8; n++) v[HDI[n]][HDJ[n]][HDK[n]] = xc[3 * n + d];
+#pragma unroll
+          for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+              const double a0 = v[0][q][r], a1 = v[1][q][r];
+              v[0][q][r] = a1 + a0;
+              v[1][q][r] = a1 - a0;
+            }
+#pragma unroll
+          for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+              const double a0 = v[q][0][r], a1 = v[q][1][r];
+              v[q][0][r] = a1 + a0;
+              v[q][1][r] = a1 - a0;
+            }
+#pragma unroll
+          for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+              const double a0 = v[q][r][0], a1 = v[q][r][1];
+              v[q][r][0] = a1 + a0;
+              v[q][r][1] = a1 - a0;
+            }
+#pragma unroll
+          for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+              for (int k = 0; k < 2; k++) c[i][j][k][d] = v[i][j][k];
+        }
+        double R0[2][2][3], R1[2][2][3], R2[2][2][3], X[2][2][2][3];
+#pragma unroll
+        for (int d = 0; d < 3; d++)
+#pragma unroll
+          for (int q = 0; q < 2; q++) {
+            const double gq = q ? GAUSS_G : -GAUSS_G;
+            const double u0 = fma(gq, c[1][1][0][d], c[1][0][0][d]), v0 = fma(gq, c[1][1][1][d], c[1][0][1][d]);  // eta = gq
+            const double u1 = fma(gq, c[1][1][0][d], c[0][1][0][d]), v1 = fma(gq, c[1][1][1][d], c[0][1][1][d]);  // xi = gq
+            const double u2 = fma(gq, c[1][0][1][d], c[0][0][1][d]);                                              // xi = gq
+            // position: e[j][k] = c0jk + xi c1jk at xi = gq
+            const double e00 = fma(gq, c[1][0][0][d], c[0][0][0][d]), e10 = u1, e01 = u2, e11 = v1;
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+              const double gr = r ? GAUSS_G : -GAUSS_G;
+              R0[q][r][d] = fma(gr, v0, u0);  // dx/dxi   at (eta_q, zeta_r)
+              R1[q][r][d] = fma(gr, v1, u1);  // dx/deta  at (xi_q, zeta_r)
+              R2[q][r][d] = fma(gr, v1, u2);  // dx/dzeta at (xi_q, eta_r)
+              const double f0 = fma(gr, e10, e00), f1 = fma(gr, e11, e01);  // eta = gr: f[k] = e[0][k] + eta e[1][k]
+              X[q][r][0][d] = 0.125 * fma(-GAUSS_G, f1, f0);
+              X[q][r][1][d] = 0.125 * fma(GAUSS_G, f1, f0);
+            }
+          }
+#pragma unroll
+        for (int ia = 0; ia < 2; ia++)
+#pragma unroll
+          for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+            for (int ic = 0; ic < 2; ic++) {
+              const double *r0 = R0[ib][ic], *r1 = R1[ia][ic], *r2 = R2[ia][ib];
+              const double a0 = fma(r1[1], r2[2], -(r1[2] * r2[1])), a1 = fma(r1[2], r2[0], -(r1[0] * r2[2])),
+                           a2 = fma(r1[0], r2[1], -(r1[1] * r2[0]));
+              const double fac = fma(r0[2], a2, fma(r0[1], a1, r0[0] * a0)) * (1.0 / 512.0);  // 1.0 * det J
+              const double *x = X[ia][ib][ic];
+              const double fv = 3.0 * PI * PI * sinpi_poly(x[0]) * sinpi_poly(x[1]) * sinpi_poly(x[2]);
+              const int p = hex_idx(ia, ib, ic);
+#pragma unroll
+              for (int i = 0; i < 8; i++) F[i] += fac * fv * c_tab3.N[p][i];
+            }
       }
     } else if (a.mat_layout == 0) {
       const double *q = a.gp + (ex + mx * (ey + my * (ez - s.mat_e_ks))) * a.mat_stride;

@@ -645,6 +645,24 @@ def test_p3_general_kernels_tensor_product_element_matrix_and_node_row(env, monk
     plan.close()
 
 
+def test_p3_general_load_tensor_product_form_and_as_stated(env):
+    """the Poisson load on general hexahedra: the default (Hadamard geometry, one-polynomial sinpi) and the
+    per-Gauss-point statement (option "rhs_simple", the library's sinpi) both match the oracle; coordinates outside
+    [0, 1] (a shifted, scaled mesh: arguments of sin(pi x) up to 7) exercise the argument reduction"""
+    O = env["O"]
+    M, N, P = 12, 7, 9
+    for shift, scale in ((0.0, 1.0), (-3.25, 2.5), (4.5, 1.0)):
+        case = make_case(env, "p3", (M, N, P), perturb=True)
+        co = np.ascontiguousarray(case["coords"] * scale + shift)
+        K, b = O.assemble_poisson3d(M, N, P, co, case["rp"], case["ci"])
+        case2 = dict(case, coords=co, K=K, b=b)
+        for opts in (None, {"rhs_simple": 1}):
+            plan, vals, gb = gpu_assemble(env, case2, options=opts)
+            assert rel(gb, b) <= TOL, (shift, scale, opts, rel(gb, b))
+            assert rel(vals, K) <= TOL
+            plan.close()
+
+
 @pytest.mark.parametrize("zc", [1, 2, 5])
 def test_p3_hex_node_layers_per_workgroup(env, zc):
     """k_assemble_p3_hex marches zc node layers per workgroup (option "zc"; the launch picks it from the mesh): chunks of
