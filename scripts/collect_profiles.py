@@ -18,7 +18,7 @@ DOM = {
     "poisson3d_general": ("poisson3d", "general", ["k_assemble_p3_hex"], "k_assemble_p3_hex", 256),
     "elastic2d_general": ("elastic2d", "general", ["k_assemble_ke_e2"], "k_assemble_ke_e2", 2048),
     "enriched3d": ("enriched3d", "default", ["k_enr_box<2>"], "k_enr_box<S=2>", 128),
-    "enriched3d_general": ("enriched3d", "general", ["k_enr_node<2>"], "k_enr_node<S=2>", 128),
+    "enriched3d_general": ("enriched3d", "general", ["k_enr_node<2; true>"], "k_enr_node<S=2,one material per element>", 128),
     # the two-kernel form: all of K = element matrices + segmented reduction, bytes per launch PAIR times the launch
     # pairs of a step
     "enriched3d_valu": ("enriched3d", "valu", ["k_enr_elem<2; false>", "k_enr_gather<6>"], "k_enr_elem + k_enr_gather", 128),
