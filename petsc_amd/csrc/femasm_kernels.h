@@ -27,13 +27,14 @@
 //      (PH_* macros, dumped by femasm_plan_destroy)
 //   5  the b stores of the one-pass k_assemble_e2_rect<true>
 //   7  the record stores of k_rhs_elem_elastic_runs;  8  also its arithmetic (input stream + LDS commit only)
+// femasm_hex2.h has H2_EXP and femasm_p3hex.h PH_EXP (listed there), under the same rule.
 // femasm_enriched.h: 1 removes the ring stores of k_enr_elem (the VALU-versus-MFMA contraction-only timing);
 //   k_enr_node: 11 no global stores, 12 no staging/rounds, 13 no contraction, 14 all three (phase 1 + block zero/read)
 #ifndef FEMASM_EXP
 #define FEMASM_EXP 0
 #endif
-#if (FEMASM_EXP != 0 || defined(HX_EXP)) && !defined(FEMASM_DEV)
-#error "profiling branches (-DFEMASM_EXP=n, -DHX_EXP=n) are compiled only into development builds: add -DFEMASM_DEV"
+#if (FEMASM_EXP != 0 || defined(H2_EXP) || defined(PH_EXP)) && !defined(FEMASM_DEV)
+#error "profiling branches (-DFEMASM_EXP=n, -DH2_EXP=n, -DPH_EXP=n) are compiled only into development builds: add -DFEMASM_DEV"
 #endif
 
 namespace femasm {

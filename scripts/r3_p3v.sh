@@ -1,5 +1,6 @@
 #!/bin/bash
-# Poisson general bench for the profiling builds named in EV (petsc_amd/csrc/exp/libfemasm_p<v>.so), K only
+# Poisson general bench for the profiling builds named in EV (petsc_amd/csrc/exp/libfemasm_p<v>.so, built with
+# hipcc ... -DFEMASM_DEV -DPH_EXP=<v> -o exp/libfemasm_p<v>.so femasm.hip -ldl), K only
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3; mkdir -p $O; cd $R
 for v in "" $EV; do
 lib=$R/petsc_amd/csrc/libfemasm.so; [ -n "$v" ] && lib=$R/petsc_amd/csrc/exp/libfemasm_p$v.so
