@@ -178,6 +178,8 @@ int femasm_plan_set_enriched_contraction(femasm_plan *plan, int mode);
  *   "p3_sweep"        Poisson on general hexahedra: 1 the node-row kernel, 2 the element-matrix kernel of round 2
  *                     (k_assemble_ke_p3) instead of k_assemble_p3_hex (element matrices in tensor-product form)
  *   "e2_brick"        1: plane strain on general quadrilaterals through the brick kernel for every row
+ *   "e2_lane_loads"   1: plane strain level 2, one-pass form: every lane loads its two elements' records itself
+ *                     instead of the record stream through LDS
  *   "e2_two_pass"     1: plane strain on boxes, K and b in two passes
  *   "rhs_simple"      1: Poisson load on general hexahedra per Gauss point as the reference states it (library sinpi)
  *                     instead of the tensor-product form

@@ -1722,12 +1722,22 @@ constexpr int RS2_ROW = 18, RS2_NB = 36;  // values of a CSR row / of a node blo
 // Measured at 2048^2: the fused kernel is 0.10 ms slower than the plain one and the pass it replaces
 // takes 0.15 ms, so the step gains 7 %; selectable (FEMASM_E2_TWO_PASS=1 keeps the two-pass form).
 // ---------------------------------------------------------------------------
+// COAL (round 3): the records of an element row arrive as ONE contiguous stream -- the 65 records of the wave's elements
+// are 12.5 KB of the AoS array, read as 13 non-temporal 16-B-per-lane loads a step ahead, laid out in LDS (the stage area,
+// idle at that point of the step; record stride 26 doubles: conflict-free for the lanes' 16-byte reads) and picked up by
+// the two lanes either side of each element.  Before, every lane read its two elements' 128 bytes itself: 32 loads per
+// lane and step whose 64 lanes touch 64 different records each.  2048^2, one-pass form: 0.414 -> 0.400 ms.  Needs stride
+// 24 and a 16-byte aligned array (the launch checks; otherwise COAL = false, the per-lane loads).  Not for K alone, which
+// needs a third of a record while the stream reads all of it (0.414 against 0.359 ms).  Either way the kernel takes
+// 262-287 registers where its phases need ~170: one wave per SIMD; capped at 256 it spills 20-26 values and runs 0.416 ms.
 constexpr int E2W_YC = 32;
-template <bool FUSE>
+constexpr int E2W_RST = 26, E2W_NRAW = (65 * 12 + 63) / 64;  // LDS stride of a record; 16-byte chunks per lane and element row
+template <bool FUSE, bool COAL>
 __global__ __launch_bounds__(64) void k_assemble_e2_rect(const Slab s, const KArgs a) {
   constexpr int NM = FUSE ? 16 : 8;
   constexpr int NB = RS2_NB, RUN = RS2_TX * NB, END = 24;  // END: values of the two rows of an x-end node (2 x 3 neighbours x 2 x 2)
   __shared__ __attribute__((aligned(16))) double sh_stage[END + RUN + END];
+  static_assert(66 * E2W_RST <= END + RUN + END, "the staged records alias the stage");
   const int lane = threadIdx.x;
   const int64_t M = s.dim[0];
   const int64_t i0 = a.x0 + (int64_t)blockIdx.x * RS2_TX;
@@ -1747,6 +1757,44 @@ __global__ __launch_bounds__(64) void k_assemble_e2_rect(const Slab s, const KAr
   auto yline = [&](int64_t j) {
     j = j < s.cks ? s.cks : (j > a.cke - 1 ? a.cke - 1 : j);
     return a.coords[2 * (M * (j - s.cks)) + 1];
+  };
+  // COAL: element row L as a stream (request: global -> registers, clamped, never masked; commit: registers -> LDS;
+  // fetch: the lane's two elements, doubles 8 .. 8 + NM of their records)
+  typedef double e2_d2 __attribute__((ext_vector_type(2)));
+  e2_d2 raw[COAL ? E2W_NRAW : 1];
+  const int nch = (nvx + 1) * 12;  // 16-byte chunks of the wave's nvx + 1 records
+  auto request = [&](int64_t L) {
+    const int64_t Lc = L < s.els ? s.els : (L > s.ele - 1 ? s.ele - 1 : L);
+    const e2_d2 *rowp = reinterpret_cast<const e2_d2 *>(a.gp + ((i0 - 1) + (M - 1) * (Lc - s.mat_e_ks)) * 24);
+#pragma unroll
+    for (int q = 0; q < E2W_NRAW; q++) {
+      const int c = lane + 64 * q;
+      raw[q] = __builtin_nontemporal_load(rowp + (c < nch ? c : nch - 1));
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int q = 0; q < E2W_NRAW; q++) {
+      const int c = lane + 64 * q, r = (c * 5462) >> 16, o = c - 12 * r;  // r = c / 12 (c < 832)
+      if (c < nch) *reinterpret_cast<e2_d2 *>(sh_stage + r * E2W_RST + 2 * o) = raw[q];
+    }
+  };
+  auto fetch = [&](double (*m)[NM]) {
+    const int li = (lane < nvx) ? lane : nvx - 1;
+#pragma unroll
+    for (int ox = 0; ox < 2; ox++) {
+      const e2_d2 *rp = reinterpret_cast<const e2_d2 *>(sh_stage + (li + ox) * E2W_RST + 8);
+#pragma unroll
+      for (int q = 0; q < NM / 2; q++) {
+        const e2_d2 v = rp[q];
+        m[ox][2 * q] = v.x;
+        m[ox][2 * q + 1] = v.y;
+      }
+    }
+  };
+  auto lds_sync = [&]() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
   };
   // E[4], nu[4] of the elements i-1, i of element row L (clamped to the rows this rank holds: never masked)
   auto load_mat = [&](int64_t L, double (*m)[NM]) {
@@ -1824,18 +1872,36 @@ __global__ __launch_bounds__(64) void k_assemble_e2_rect(const Slab s, const KAr
   for (int ox = 0; ox < 2; ox++)
 #pragma unroll
     for (int q = 0; q < NM; q++) mcur[ox][q] = mnext[ox][q] = 0.0;
-  load_mat(yc0 - 1, mcur);
+  if constexpr (COAL) {
+    request(yc0 - 1);
+    commit();
+    lds_sync();
+    fetch(mcur);
+    lds_sync();
+    request(yc0);
+  } else {
+    load_mat(yc0 - 1, mcur);
+  }
   double y0 = yline(yc0 - 1), y1 = yline(yc0), y2 = yline(yc0 + 1);  // rolling window of the y line: rows L, L+1, L+2
   records(yc0 - 1, y0, y1, mcur, rlo);
   if constexpr (FUSE) fe_terms(yc0 - 1, y0, y1, mcur, flo, fup);
-  load_mat(yc0, mnext);
+  if constexpr (!COAL) load_mat(yc0, mnext);
   for (int st = 0; st < ny; st++) {
     const int64_t jn = yc0 + st;
+    if constexpr (COAL) {
+      lds_sync();  // the previous step's copy-out has read the stage
+      commit();    // element row jn (requested a step ago)
+      lds_sync();
+      fetch(mcur);
+      lds_sync();
+      request(jn + 1);  // one step ahead: issued before this step's stores
+    } else {
 #pragma unroll
-    for (int ox = 0; ox < 2; ox++)
+      for (int ox = 0; ox < 2; ox++)
 #pragma unroll
-      for (int q = 0; q < NM; q++) mcur[ox][q] = mnext[ox][q];
-    load_mat(jn + 1, mnext);  // one step ahead: issued before this step's stores
+        for (int q = 0; q < NM; q++) mcur[ox][q] = mnext[ox][q];
+      load_mat(jn + 1, mnext);  // one step ahead: issued before this step's stores
+    }
     y0 = y1;
     y1 = y2;
     y2 = yline(jn + 2);

@@ -645,6 +645,21 @@ def test_p3_general_kernels_tensor_product_element_matrix_and_node_row(env, monk
     plan.close()
 
 
+@pytest.mark.parametrize("dims", [(140, 7), (67, 12), (5, 40)])
+def test_e2_one_pass_record_stream_and_lane_loads(env, dims):
+    """k_assemble_e2_rect<one pass>: the records of an element row as one stream through LDS (default since round 3) and
+    loaded lane by lane (option "e2_lane_loads"): the same K and b bit for bit (the arithmetic is the same), both within
+    the tolerance of the oracle; runs of 64, 64 and 10 nodes, 64 and 1, and a single short run"""
+    case = make_case(env, "e2", dims, perturb=False, vary_material=False)
+    plan, vals, gb = gpu_assemble(env, case)
+    assert plan.fast_path() == 2
+    plan2, vals2, gb2 = gpu_assemble(env, case, options={"e2_lane_loads": 1})
+    assert plan2.fast_path() == 2
+    assert rel(vals, case["K"]) <= TOL and rel(gb, case["b"]) <= TOL
+    assert np.array_equal(vals, vals2) and np.array_equal(gb, gb2)
+    plan.close(); plan2.close()
+
+
 def test_p3_general_load_tensor_product_form_and_as_stated(env):
     """the Poisson load on general hexahedra: the default (Hadamard geometry, one-polynomial sinpi) and the
     per-Gauss-point statement (option "rhs_simple", the library's sinpi) both match the oracle; coordinates outside
