@@ -260,7 +260,7 @@ def kernel_name(wl, level, args):
     if wl == "elastic2d":
         return "k_assemble_e2_rect" if level == 2 else "k_assemble_ke_e2"
     if wl == "poisson3d":
-        return {2: "k_assemble_p3_rect", 1: "k_assemble_rowsweep<POISSON3D>"}.get(level, "k_assemble_p3_hex")
+        return {2: "k_assemble_p3_rect", 1: "k_assemble_rowsweep<POISSON3D>"}.get(level, "k_assemble_p3_hex4")
     return {2: "k_assemble_s3_unit", 1: "k_assemble_s3_hex2"}.get(level, "k_assemble_sweep<ELASTIC3D>")
 
 

@@ -176,11 +176,13 @@ int femasm_plan_set_enriched_contraction(femasm_plan *plan, int mode);
  *   "enr_scratch_mb"  enriched kind, two-kernel form: size of the element-matrix ring
  *   "s3_rowsweep"     1: elastic boxes through k_assemble_rowsweep<ELASTIC> instead of k_assemble_s3_unit
  *   "p3_sweep"        Poisson on general hexahedra: 1 the node-row kernel, 2 the element-matrix kernel of round 2
- *                     (k_assemble_ke_p3) instead of k_assemble_p3_hex (element matrices in tensor-product form)
+ *                     (k_assemble_ke_p3) instead of k_assemble_p3_hex4 (element matrices in tensor-product form)
  *   "e2_brick"        1: plane strain on general quadrilaterals through the brick kernel for every row
  *   "e2_lane_loads"   1: plane strain level 2, one-pass form: every lane loads its two elements' records itself
  *                     instead of the record stream through LDS
  *   "e2_two_pass"     1: plane strain on boxes, K and b in two passes
+ *   "p3_hex2w"        1: Poisson on general hexahedra: k_assemble_p3_hex (every wave does every phase) instead of
+ *                     k_assemble_p3_hex4 (element waves and row waves)
  *   "rhs_simple"      1: Poisson load on general hexahedra per Gauss point as the reference states it (library sinpi)
  *                     instead of the tensor-product form
  *   "enr_rhs_simple"  1: enriched kind, the per-element right-hand side

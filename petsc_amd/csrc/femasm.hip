@@ -233,6 +233,7 @@ struct femasm_plan {
     int e2_lane_loads = 0;       // E2 level 2: every lane loads its two elements' records itself (round 2) instead of the stream
     int e2_brick = 0;            // E2 general: the brick kernel for every row instead of k_assemble_ke_e2
     int e2_two_pass = 0;         // E2 boxes: K and b in two passes
+    int p3_hex2w = 0;            // P3 general: the two-wave form of k_assemble_p3_hex instead of the four-wave form
     int rhs_simple = 0;          // P3 general: the load per Gauss point as the reference states it (library sinpi)
     int enr_rhs_simple = 0;      // enriched kind: the per-element RHS
     int debug = 0;               // prints launch facts to stderr
@@ -532,8 +533,11 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
           // kernel of round 2, 1: the node-row kernel of round 1, for A/B)
           // node layers per workgroup: a chunk of zc node layers sweeps zc + 1 element layers, and the last round of the
           // resident workgroups (two per CU: one wave per SIMD) should be full (256^3: 16 -> 1.61 ms, 32 -> 1.57 ms)
-          const int64_t tiles = ((b.x1 - b.x0 + PH_TX - 1) / PH_TX) * ((b.y1 - b.y0 + PH_TY - 1) / PH_TY);
-          const int64_t nz = z1 - z0, resident = (int64_t)p->ncu * 2;
+          // (the default kernel: one eight-wave workgroup per CU on two x-neighbouring tiles; the two-wave form: two
+          // workgroups per CU on one tile each)
+          const int64_t ntx = (b.x1 - b.x0 + PH_TX - 1) / PH_TX, nty = (b.y1 - b.y0 + PH_TY - 1) / PH_TY;
+          const int64_t tiles = (p->opt.p3_hex2w ? ntx : (ntx + 1) / 2) * nty;
+          const int64_t nz = z1 - z0, resident = (int64_t)p->ncu * (p->opt.p3_hex2w ? 2 : 1);
           int64_t zc = nz;
           double best = -1.0;
           for (int64_t chunks = 1; chunks <= nz; chunks++) {
@@ -549,7 +553,8 @@ int launch_K(femasm_plan *p, const femasm_material *mat, int bc, double *out, in
           if (p->opt.debug) fprintf(stderr, "[femasm] poisson level 0: %lld tiles, %lld node layers per workgroup\n", (long long)tiles, (long long)zc);
           dim3 gph((unsigned)((b.x1 - b.x0 + PH_TX - 1) / PH_TX), (unsigned)((b.y1 - b.y0 + PH_TY - 1) / PH_TY),
                    (unsigned)((nz + zc - 1) / zc));
-          hipLaunchKernelGGL(k_assemble_p3_hex, gph, dim3(PH_NT), 0, p->stream, p->s, az);
+          if (p->opt.p3_hex2w) hipLaunchKernelGGL(k_assemble_p3_hex, gph, dim3(PH_NT), 0, p->stream, p->s, az);
+          else hipLaunchKernelGGL(k_assemble_p3_hex4, dim3((gph.x + 1) / 2, gph.y, gph.z), dim3(512), 0, p->stream, p->s, az);
         } else if (KIND == KIND_POISSON && p->opt.p3_sweep != 1) {
           dim3 gke((unsigned)((b.x1 - b.x0 + KE_TX - 1) / KE_TX), (unsigned)((b.y1 - b.y0 + KE_TY - 1) / KE_TY),
                    (unsigned)((z1 - z0 + KE_ZC - 1) / KE_ZC));
@@ -1130,6 +1135,16 @@ int femasm_plan_destroy(femasm_plan *p) {
   if (!p) return FEMASM_OK;
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
+#if PH_EXP == 8
+  {  // wave placement of k_assemble_p3_hex4 (profiling build)
+    unsigned long long t[32];
+    if (p->bad && hipMemcpy(t, p->bad, sizeof t, hipMemcpyDeviceToHost) == hipSuccess && t[8] + t[9] + t[10] + t[11]) {
+      for (int w = 0; w < 8; w++)  // (SIMD + 1 of wave w in four sample workgroups, one byte each, summed over the launches)
+        fprintf(stderr, "[femasm p3hex4 placement] wave %d: %llx\n", w, t[8 + w]);
+      fprintf(stderr, "[femasm p3hex4 placement] element waves on SIMD 0..3: %llu %llu %llu %llu\n", t[24], t[25], t[26], t[27]);
+    }
+  }
+#endif
 #if PH_EXP == 9
   {  // phase clocks of k_assemble_p3_hex (profiling build): summed over all waves and launches, per wave-step
     unsigned long long t[32];
@@ -1207,6 +1222,7 @@ int femasm_plan_set_option(femasm_plan *p, const char *name, int64_t value) {
   else if (n == "e2_brick") o.e2_brick = value != 0;
   else if (n == "e2_lane_loads") o.e2_lane_loads = value != 0;
   else if (n == "e2_two_pass") o.e2_two_pass = value != 0;
+  else if (n == "p3_hex2w") o.p3_hex2w = value != 0;
   else if (n == "rhs_simple") o.rhs_simple = value != 0;
   else if (n == "enr_rhs_simple") o.enr_rhs_simple = value != 0;
   else if (n == "debug") o.debug = value != 0;

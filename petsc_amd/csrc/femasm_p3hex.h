@@ -43,7 +43,7 @@
 
 #ifndef PH_EXP
 #define PH_EXP 0  // profiling builds only (-DPH_EXP=n): 1 no global stores, 2 no element arithmetic, 4 no gather,
-#endif            // 9 phase clocks (printed when the plan is destroyed)
+#endif            // 8 wave placement of k_assemble_p3_hex4, 9 phase clocks (printed when the plan is destroyed)
 #if PH_EXP == 9
 #define PHX(q) do { const unsigned long long n_ = __builtin_readcyclecounter(); phc[q] += n_ - pht; pht = n_; } while (0)
 #else
@@ -108,7 +108,7 @@ __device__ inline void ph_off_table(const double (&P)[2][2][2], double (&T)[2][2
 // the 36 unique entries of the element matrix of the hexahedron with nodes xs (LDS: 3 doubles per node, node (cx, cy, cz)
 // of the halo'd tile at 3 (cx + PH_HX (cy + PH_HY cz'))), cz' the ring slot) -> ke[36].  Returns the number of Gauss points
 // with det J <= 0 (or NaN).  scale: 1 for an element that is assembled here, 0 otherwise (its matrix is zero).
-__device__ inline int ph_element_matrix(const double *__restrict__ xlo, const double *__restrict__ xhi, double scale,
+__device__ __forceinline__ int ph_element_matrix(const double *__restrict__ xlo, const double *__restrict__ xhi, double scale,
                                         double *__restrict__ ke) {
   // ---- Hadamard coefficients c[i][j][k][component] (unnormalised: 8 x the polynomial coefficients) ----
   double c[2][2][2][3];
@@ -419,6 +419,192 @@ __global__ __launch_bounds__(PH_NT) void k_assemble_p3_hex(const Slab s, const K
     atomicAdd(a.bad + 16, (unsigned long long)nsteps);
   }
 #endif
+}
+
+// ---------------------------------------------------------------------------
+// k_assemble_p3_hex4: the same arithmetic with the element phase and the rows in DIFFERENT waves.  k_assemble_p3_hex
+// needs ~330 registers (the element phase ~190 of them, the carry, the rows, the copy-out) and so holds one wave per
+// SIMD: nothing overlaps a wave's element phase, the SIMDs are half idle.  Here four waves work on a 16 x 8 element tile:
+//   two element waves  lane = element: coordinates (requested a step ahead), element matrices of layer L -> sh_ke
+//   two row waves      lane = node: gather from sh_ke (the carry stays in THEIR registers), rows -> their own stage ->
+//                      CSR array; a row wave owns whole tile rows (0-3, 4-6), so staging and copy-out need no
+//                      workgroup barrier
+// and two barriers per step: X (sh_ke complete) and Y (the gather is through: sh_ke may be overwritten).  The row waves'
+// staging and stores of layer L run beside the element waves' layer L + 1.  Neither role needs more than 256 registers
+// (207): two waves per SIMD.  A workgroup is EIGHT waves on two x-neighbouring tiles (145 KB of LDS, one per CU), so that
+// which SIMD holds what is fixed: see the wave roles below (they decide speed, not results).
+// ---------------------------------------------------------------------------
+constexpr int PH4_STG = 16 + PH_TY * PH_RS + 512;  // the stage: 16 doubles of head-room, 7 rows, read slack of the copy-out
+
+__global__ __launch_bounds__(512, 2) void k_assemble_p3_hex4(const Slab s, const KArgs a) {
+  if (a.cond && a.bad[1] == 0) return;
+  constexpr int NXL = PH_HX * PH_HY, NXD = 3 * NXL;
+  constexpr int NLD = (NXD + 127) / 128;
+  __shared__ __attribute__((aligned(16))) double sh_ke2[2][128 * KE_KS];
+  __shared__ __attribute__((aligned(16))) double sh_stg2[2][PH4_STG];
+  __shared__ double sh_x2[2][2 * NXD];
+  const int w8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  // two tiles per workgroup, x-neighbours: waves 0-3 the first, 4-7 the second.  The hardware places the waves of a
+  // workgroup on the SIMDs s, s+2, s+1, s+3, s, s+2, s+1, s+3 (measured, PH_EXP = 8): with the element waves 0, 1 of the
+  // first tile and 6, 7 of the second every SIMD holds one element wave and one row wave
+  const int half = w8 >> 2, w = w8 & 3;
+  const bool element_wave = half ? (w >= 2) : (w < 2);
+#if PH_EXP == 8  // where the waves sit: histogram of (wave of the workgroup, SIMD) and of the element waves per SIMD
+  if (lane == 0) {
+    const unsigned simd = __builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);  // HW_REG_HW_ID, bits 5:4
+    if (blockIdx.x == 0 && blockIdx.y < 4 && blockIdx.z == 0) atomicAdd(a.bad + 8 + w8, (unsigned long long)(simd + 1) << (8 * blockIdx.y));
+    if (element_wave) atomicAdd(a.bad + 24 + simd, 1ULL);
+  }
+#endif
+  double *sh_ke = sh_ke2[half], *sh_stg = sh_stg2[half], *sh_x = sh_x2[half];
+  const int tid = ((w & 1) << 6) | lane;                  // 0 .. 127 within the role
+  const int lx = tid & 15, ly = tid >> 4;
+  const int64_t M = s.dim[0], N = s.dim[1];
+  const int64_t i0 = a.x0 + ((int64_t)blockIdx.x * 2 + half) * PH_TX, j0 = a.y0 + (int64_t)blockIdx.y * PH_TY;
+  const int64_t zc0 = a.s0 + (int64_t)blockIdx.z * a.zc;
+  const int64_t zc1 = (zc0 + a.zc < a.s1) ? zc0 + a.zc : a.s1;
+  const int nsteps = (int)(zc1 - zc0) + 1;
+  // (an odd number of tiles in x: the last workgroup's second tile is empty -- nvx = 0, its waves keep the barriers)
+  const int nvx = (a.x1 - i0 < PH_TX) ? (a.x1 > i0 ? (int)(a.x1 - i0) : 0) : PH_TX;
+  const int nvy = (a.y1 - j0 < PH_TY) ? (int)(a.y1 - j0) : PH_TY;
+
+  if (element_wave) {
+    const int64_t gex = i0 - 1 + lx, gey = j0 - 1 + ly;
+    const bool exy_ok = gex >= 0 && gex < M - 1 && gey >= 0 && gey < N - 1;
+    unsigned xoff[NLD];  // (the launch checks 3 M N < 2^31)
+#pragma unroll
+    for (int q = 0; q < NLD; q++) {
+      int d = tid + 128 * q;
+      d = d < NXD ? d : NXD - 1;
+      const int cy = d / (3 * PH_HX), col = d - 3 * PH_HX * cy, cx = col / 3, comp = col - 3 * cx;
+      int64_t gi = i0 - 1 + cx, gj = j0 - 1 + cy;
+      gi = gi < 0 ? 0 : (gi > M - 1 ? M - 1 : gi);
+      gj = gj < 0 ? 0 : (gj > N - 1 ? N - 1 : gj);
+      xoff[q] = (unsigned)(3 * (gi + M * gj) + comp);
+    }
+    double xn[NLD];
+    auto request_layer = [&](int64_t gk) {
+      gk = gk < s.cks ? s.cks : (gk > a.cke - 1 ? a.cke - 1 : gk);
+      const double *base = a.coords + 3 * M * N * (gk - s.cks);
+#pragma unroll
+      for (int q = 0; q < NLD; q++) xn[q] = base[xoff[q]];
+    };
+    auto commit_layer = [&](int slot) {
+#pragma unroll
+      for (int q = 0; q < NLD; q++)
+        if (q < NLD - 1 || tid < NXD - 128 * (NLD - 1)) sh_x[slot * NXD + tid + 128 * q] = xn[q];
+    };
+    request_layer(zc0 - 1);
+    commit_layer(0);
+    request_layer(zc0);
+    commit_layer(1);
+    for (int st = 0; st < nsteps; st++) {
+      const int64_t L = zc0 - 1 + st;
+      if (st + 1 < nsteps) request_layer(L + 2);
+      // Y of the previous step (at st = 0: the barrier that makes the two staged layers visible to both element waves)
+      __syncthreads();
+      const bool eok = exy_ok && L >= s.els && L < s.ele;
+      const double *xlo = sh_x + (st & 1) * NXD + 3 * (lx + PH_HX * ly);
+      const double *xhi = sh_x + ((st + 1) & 1) * NXD + 3 * (lx + PH_HX * ly);
+      const int nbad = ph_element_matrix(xlo, xhi, eok ? 1.0 / 512.0 : 0.0, sh_ke + tid * KE_KS);
+      if (eok && nbad) atomicAdd(a.bad, (unsigned long long)nbad);
+      // node layer L + 2 over node layer L.  Both element waves must be through layer L first: they are not until X, so
+      // the commit waits for it (the row waves gather meanwhile)
+      __syncthreads();  // X: sh_ke complete
+      if (st + 1 < nsteps) commit_layer(st & 1);
+    }
+    __syncthreads();  // Y of the last step
+  } else {
+    const int n = nvx * 27;
+    const bool mynode = lx < nvx && ly < nvy;
+    const int glx = (lx < PH_TX) ? lx : 0, gly = (ly < PH_TY) ? ly : 0;
+    double lower[9], mid[9];
+#pragma unroll
+    for (int q = 0; q < 9; q++) lower[q] = mid[q] = 0.0;
+    double *const o00 = a.out + (row_start(s, i0, j0, zc0, 0) - a.base_off);
+    const int64_t sj = row_start(s, i0, j0 + 1, zc0, 0) - row_start(s, i0, j0, zc0, 0);
+    const int64_t sk = row_start(s, i0, j0, zc0 + 1, 0) - row_start(s, i0, j0, zc0, 0);
+    const unsigned sji = __builtin_amdgcn_readfirstlane((unsigned)sj);
+    double *oL = o00;
+    double *stg = sh_stg + 16;
+    const int r0 = 4 * (w & 1);  // this wave's tile rows: r0 .. r0 + 3 (row 7 does not exist)
+    auto wave_sync = [&]() {
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    };
+    __syncthreads();  // (the element waves' first barrier)
+    for (int st = 0; st < nsteps; st++) {
+      const int64_t L = zc0 - 1 + st;
+      __syncthreads();  // X: the element matrices of layer L
+      double row[27];
+      const bool finish = st >= 1, start = st < nsteps - 1;
+      if (finish) {
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+          row[q] = lower[q];
+          row[9 + q] = mid[q];
+          row[18 + q] = 0.0;
+        }
+        ke_gather_p3<0, 0>(sh_ke, glx, gly, row + 9);
+        ke_gather_p3<0, 1>(sh_ke, glx, gly, row + 18);
+      }
+      if (start) {
+#pragma unroll
+        for (int q = 0; q < 9; q++) lower[q] = mid[q] = 0.0;
+        ke_gather_p3<1, 0>(sh_ke, glx, gly, lower);
+        ke_gather_p3<1, 1>(sh_ke, glx, gly, mid);
+      }
+      __syncthreads();  // Y: the gather is through (the element waves' next step, or their final barrier)
+      if (!finish) continue;
+      const unsigned oLi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<uintptr_t>(oL) >> 3));
+      wave_sync();  // this wave's copy-out of the previous step has read its rows of the stage
+      if (mynode) {
+        double *dst = stg + ly * PH_RS + ((oLi + ly * sji) & 1) + lx * 27;
+#pragma unroll
+        for (int q = 0; q < 27; q++) dst[q] = row[q];
+      }
+      wave_sync();
+      double2 v[4][4];
+      const unsigned e0 = 2u * (unsigned)lane;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int rr = r0 + u;
+        const unsigned head = (oLi + rr * sji) & 15u;
+        const double *src = stg + rr * PH_RS - (int)(head & ~1u);
+#pragma unroll
+        for (int it = 0; it < 4; it++) v[u][it] = *reinterpret_cast<const double2 *>(src + e0 + 128u * it);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int rr = r0 + u;
+        if (rr < nvy) {
+          const unsigned head = (oLi + rr * sji) & 15u;
+          double *bal = oL + rr * sj - head;
+#pragma unroll
+          for (int it = 0; it < 4; it++) {
+            const unsigned e = e0 + 128u * it;
+            if (e >= head && e + 1 < head + n) {
+#if PH_EXP == 1
+              asm volatile("" ::"v"(v[u][it].x), "v"(v[u][it].y));
+#else
+              store_pair(bal + e, v[u][it]);
+#endif
+            }
+          }
+        }
+      }
+      if (lane < 8) {  // the odd double at either end of a run: lane u the head of this wave's row u, lane 4 + u its tail
+        const int rr = r0 + (lane & 3), tail = lane >> 2;
+        const int head = (int)((oLi + rr * sji) & 15);
+        const bool odd = tail ? ((head + n) & 1) : (head & 1);
+        if (rr < nvy && odd && n > 0) {
+          const int t = tail ? n - 1 : 0;
+          (oL + rr * sj)[t] = stg[rr * PH_RS + (head & 1) + t];
+        }
+      }
+      oL += sk;
+    }
+  }
 }
 
 }  // namespace femasm

@@ -15,7 +15,7 @@ DOM = {
     "elastic2d": ("elastic2d", "default", ["k_assemble_e2_rect"], "k_assemble_e2_rect", 2048),
     "elastic3d_manufactured": ("elastic3d", "manufactured", ["k_assemble_s3_unit"], "k_assemble_s3_unit", 128),
     "elastic3d_general": ("elastic3d", "general", ["k_assemble_s3_hex2"], "k_assemble_s3_hex2", 128),
-    "poisson3d_general": ("poisson3d", "general", ["k_assemble_p3_hex"], "k_assemble_p3_hex", 256),
+    "poisson3d_general": ("poisson3d", "general", ["k_assemble_p3_hex4"], "k_assemble_p3_hex4", 256),
     "elastic2d_general": ("elastic2d", "general", ["k_assemble_ke_e2"], "k_assemble_ke_e2", 2048),
     "enriched3d": ("enriched3d", "default", ["k_enr_box<2>"], "k_enr_box<S=2>", 128),
     "enriched3d_general": ("enriched3d", "general", ["k_enr_node<2; true>"], "k_enr_node<S=2,one material per element>", 128),

@@ -629,15 +629,17 @@ def test_element_soa_material_on_an_upper_slab(env, mesh):
     plan.close()
 
 
-@pytest.mark.parametrize("kernel", ["hex", "ke", "sweep"])
+@pytest.mark.parametrize("kernel", ["hex", "hex2w", "ke", "sweep"])
 @pytest.mark.parametrize("dims", [(33, 9, 21), (17, 5, 4), (4, 3, 5), (47, 12, 35), (18, 10, 3), (3, 3, 40)])
 def test_p3_general_kernels_tensor_product_element_matrix_and_node_row(env, monkeypatch, kernel, dims):
-    """Poisson K on general hexahedra has three kernels: k_assemble_p3_hex (default since round 3: the element matrix in
-    tensor-product form, 15 x 7 node tiles), k_assemble_ke_p3 (option "p3_sweep" = 2: the 36 unique entries of each
-    element matrix from literal reference gradients, 15 x 3 node tiles) and the node-row kernel k_assemble_sweep_p3
-    ("p3_sweep" = 1).  All against the oracle on perturbed meshes whose extents are not multiples of any tile."""
+    """Poisson K on general hexahedra has four kernels: k_assemble_p3_hex4 (default since round 3: the element matrix in
+    tensor-product form, 15 x 7 node tiles, element waves and row waves, two tiles per workgroup), k_assemble_p3_hex
+    (option "p3_hex2w": the same arithmetic, every wave does every phase), k_assemble_ke_p3 (option "p3_sweep" = 2: the
+    36 unique entries of each element matrix from literal reference gradients, 15 x 3 node tiles) and the node-row
+    kernel k_assemble_sweep_p3 ("p3_sweep" = 1).  All against the oracle on perturbed meshes whose extents are not
+    multiples of any tile (odd and even numbers of tiles in x: the second tile of the last workgroup empty or not)."""
     case = make_case(env, "p3", dims, perturb=True)
-    opts = {"hex": None, "ke": {"p3_sweep": 2}, "sweep": {"p3_sweep": 1}}[kernel]
+    opts = {"hex": None, "hex2w": {"p3_hex2w": 1}, "ke": {"p3_sweep": 2}, "sweep": {"p3_sweep": 1}}[kernel]
     plan, vals, gb = gpu_assemble(env, case, options=opts)
     assert plan.fast_path() == 0
     assert not np.isnan(vals).any()
@@ -684,6 +686,9 @@ def test_p3_hex_node_layers_per_workgroup(env, zc):
     one, two and five layers over 11 interior layers give the same K bit for bit as the launch's own choice"""
     case = make_case(env, "p3", (20, 11, 13), perturb=True)
     plan0, vals0, _ = gpu_assemble(env, case)
+    plan2, vals2w, _ = gpu_assemble(env, case, options={"p3_hex2w": 1})
+    assert np.array_equal(vals2w, vals0)                                 # the two forms do the same arithmetic
+    plan2.close()
     plan, vals, gb = gpu_assemble(env, case, options={"zc": zc})
     assert rel(vals, case["K"]) <= TOL and rel(gb, case["b"]) <= TOL
     assert np.array_equal(vals, vals0)
