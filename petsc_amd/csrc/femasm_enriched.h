@@ -790,6 +790,7 @@ __global__ __launch_bounds__(64 * EnrNodeCfg<S>::NW) void k_enr_node(const Slab 
 //     block's eight stores waits for their acknowledgement (1.2 of 9.1 ms before this);
 //   * 13.4 KB of LDS per wave and <= 168 registers: 12 waves per CU (k_enr_node: 8).
 // ---------------------------------------------------------------------------
+constexpr int ENR_YS = 16;  // y-lines of a strip in k_enr_box's node order (4, 8, 16: 8.06-8.22, 8.19, 8.02-8.13 ms)
 template <int S> struct EnrBoxCfg {
   static constexpr int NE = S - 1, D = 3 * S;
   static constexpr int SB = (S <= 2) ? S : 1;  // row families per contraction pass (9 S SB accumulators)
@@ -826,10 +827,35 @@ __global__ __launch_bounds__((64 * EnrBoxCfg<S>::NW)) void k_enr_box(const Slab 
   const int ox = (e & 1) - 1, oy = ((e >> 1) & 1) - 1, oz = (e >> 2) - 1;
   const int arow = hex_idx(-ox, -oy, -oz);  // the node itself in element e
   const int64_t nn = M * N * (a.s1 - a.s0);
-  const int64_t q0 = ((int64_t)blockIdx.x * NW + w) * a.npw;
+  // Order of the nodes (round 3; each node's block is written by one wave whatever the order): an element's record is read
+  // by the waves of its eight nodes, which lie on four x-lines (j, k), (j+1, k), (j, k+1), (j+1, k+1).  In the natural
+  // order those lines are a plane apart (11 MB of records) and on different XCDs (workgroup b runs on XCD b % 8), so a
+  // record came from HBM 3.3 times (4.6 GB read for 1.4 GB of records).  Now the lines go strip by strip -- ENR_YS
+  // y-lines, all node layers of the pass, then the next strip -- so the four lines are 2 * ENR_YS lines apart, and the
+  // workgroups of an XCD take consecutive stretches of that order (lb below): 3.4 GB read, the kernel's traffic 21.1 ->
+  // 19.9 GB = 1.14 x its algorithmic bytes.  Its time does not change (8.09 -> 8.13 ms on one box): it is not bound by
+  // its reads.
+  const unsigned nb = gridDim.x, bq = nb >> 3, br = nb & 7u, xcd = blockIdx.x & 7u;
+  const int64_t lb = (int64_t)xcd * bq + (xcd < br ? xcd : br) + (blockIdx.x >> 3);
+  const int64_t q0 = (lb * NW + w) * a.npw;
   const int nq = (int)((nn - q0 < a.npw) ? (nn - q0 > 0 ? nn - q0 : 0) : a.npw);
-  // (the wave's nodes are consecutive in the natural order: decoded once, then advanced)
-  int ii = (int)(q0 % M), jj = (int)((q0 / M) % N), kk_ = (int)(a.s0 + q0 / (M * N));
+  // (the wave's nodes are consecutive in that order: decoded once, then advanced)
+  const int nk = (int)(a.s1 - a.s0);
+  int ii, jj, kk_, j_lo, j_hi;  // j_lo, j_hi: the strip
+  {
+    const int64_t line = q0 / M;
+    ii = (int)(q0 - line * M);
+    const int64_t per_strip = (int64_t)ENR_YS * nk;
+    int64_t st = line / per_strip;
+    const int64_t nstrips = (N + ENR_YS - 1) / ENR_YS;
+    if (st >= nstrips) st = nstrips - 1;  // (q0 beyond the last node: nq = 0)
+    j_lo = (int)(st * ENR_YS);
+    j_hi = (j_lo + ENR_YS < (int)N) ? j_lo + ENR_YS : (int)N;
+    const int64_t r = line - st * per_strip;  // line within the strip: layer-major, then y (a short last strip: h < ENR_YS)
+    const int h = j_hi - j_lo;
+    kk_ = (int)(a.s0 + r / h);
+    jj = j_lo + (int)(r % h);
+  }
   int actp = 0;
 
   // ---- phase 1, lane (e, p): the element's box, premise, coefficients, (phi, grad phi), the row node's gradients ----
@@ -1033,7 +1059,15 @@ __global__ __launch_bounds__((64 * EnrBoxCfg<S>::NW)) void k_enr_box(const Slab 
     // ---- the next node's phase 1 BEFORE this node's stores (see the header) ----
     if (++ii == (int)M) {
       ii = 0;
-      if (++jj == (int)N) jj = 0, kk_++;
+      if (++jj == j_hi) {
+        jj = j_lo;
+        if (++kk_ == (int)a.s1) {  // the next strip
+          kk_ = (int)a.s0;
+          j_lo = j_hi;
+          j_hi = (j_lo + ENR_YS < (int)N) ? j_lo + ENR_YS : (int)N;
+          jj = j_lo;
+        }
+      }
     }
     if (qi + 1 < nq) phase1(ii, jj, kk_);
     // ---- the block -> CSR array, 16 B per lane from the 128-byte boundary below it ----
