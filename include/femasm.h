@@ -152,8 +152,9 @@ int femasm_plan_set_stream(femasm_plan *plan, void *stream);
  *   level 0  general isoparametric elements, (E,nu) per Gauss point
  * The premise is tested exactly on every node / element touched (bitwise-equal coordinates, edge
  * vectors and material); on any failure femasm_assemble_system reassembles K one level down
- * (Poisson 2 -> 1 -> 0; elastic and enriched 2 -> 1 -> 0, and 2 -> 0 at once when the failed premise is the
- * material's, which level 1 shares) and the plan stays there.  Default 2.
+ * (elastic and enriched 2 -> 1 -> 0, and 2 -> 0 at once when the failed premise is the material's, which level 1
+ * shares; Poisson 2 -> 0: its level 1 is kept for callers that set it, the general kernel is the faster one) and the
+ * plan stays there.  Default 2.
  * Results of the levels differ by rounding only. */
 int femasm_plan_set_fast_path(femasm_plan *plan, int level);
 int femasm_plan_get_fast_path(femasm_plan *plan, int *level);

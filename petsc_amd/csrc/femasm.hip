@@ -259,7 +259,7 @@ int finish_pending(femasm_plan *p) {
   flags[0] = flags[1] = flags[2] = 0;
   HIPCHK(hipMemcpyAsync(flags, p->bad, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, p->stream));
   HIPCHK(hipStreamSynchronize(p->stream));
-  if (p->pending_fast && flags[1]) p->fast_level = (p->kind != KIND_PLANE && p->fast_level == 2) ? 1 : 0;  // as the synchronous loop
+  if (p->pending_fast && flags[1]) p->fast_level = (p->kind == KIND_ELASTIC && p->fast_level == 2) ? 1 : 0;  // as the synchronous loop
   p->pending_fast = false;
   if (flags[2]) return fail(FEMASM_ERR_HIP, "internal: %llu wave hand-shakes of the row-sweep kernel timed out", flags[2]);
   if (flags[0]) return fail(FEMASM_ERR_GEOMETRY, "%llu Gauss points with non-positive or NaN det(J) (reported by the "
@@ -1473,10 +1473,11 @@ int femasm_assemble_system(femasm_plan *p, const femasm_material *mat, const fem
   double k_ms_redo = -1.0;
   while (d_vals && p->used_fast && flags[1]) {
     // The fast kernels verify their premise exactly (level 2: rectilinear mesh, one (E,nu) per
-    // element; Poisson level 1: parallelepiped elements).  The test failed somewhere: the plan drops
-    // a level for good (Poisson 2 -> 1 -> 0, elastic 2 -> 0) and K is assembled again, overwriting
-    // every value of the previous attempt.
-    p->fast_level = (p->kind != KIND_PLANE && p->fast_level == 2) ? 1 : 0;
+    // element; level 1: elastic, one (E,nu) per element; Poisson, only when the caller set it: parallelepipeds).  The
+    // test failed somewhere: the plan drops for good (elastic 2 -> 1 -> 0; Poisson 2 -> 0, 1 -> 0: since round 3 its
+    // general kernel is faster than the parallelepiped kernel, 1.26 against 1.51 ms at 256^3) and K is assembled again,
+    // overwriting every value of the previous attempt.
+    p->fast_level = (p->kind == KIND_ELASTIC && p->fast_level == 2) ? 1 : 0;
     p->used_fast = false;
     HIPCHK(hipMemsetAsync(p->bad, 0, 3 * sizeof(unsigned long long), p->stream));
     rc = launch_rect_check(p);  // (only if the plan is still at level 2, which it is not)

@@ -799,15 +799,25 @@ def test_sheared_mesh_elastic_falls_back_poisson_stays_fast(env):
     assert plan.fast_path() == 1  # parallelepipeds are not boxes: the hexahedron kernel (one material per element)
     assert rel(vals, case["K"]) <= TOL and rel(b, case["b"]) <= TOL
     plan.close()
-    # Poisson's fast kernel takes any parallelepiped
+    # Poisson: the plan goes from level 2 straight to level 0 (since round 3 the general kernel k_assemble_p3_hex4 is
+    # faster than the parallelepiped kernel of level 1); level 1, set by the caller, takes any parallelepiped and stays
     M, N, P = dims
     rp, ci = O.pattern(3, 1, M, N, P)
     K, bb = O.assemble_poisson3d(M, N, P, case["coords"], rp, ci)
     pc = dict(problem=env["F"].POISSON3D_Q1, dims=dims, coords=case["coords"], props=None, stride=0,
               bc=env["F"].BC_POISSON_INLOOP, rp=rp, ci=ci, K=K, b=bb)
     plan, vals, b = gpu_assemble(env, pc)
-    assert plan.fast_path() >= 1
+    assert plan.fast_path() == 0
     assert rel(vals, K) <= TOL and rel(b, bb) <= TOL
+    plan.close()
+    torch, F, dev = env["torch"], env["F"], env["dev"]
+    plan = F.Plan(F.POISSON3D_Q1, M, N, P, coords=torch.from_numpy(case["coords"]).to(dev))
+    plan.set_fast_path(1)
+    v1 = torch.full((plan.nnz,), float("nan"), dtype=torch.float64, device=dev)
+    b1 = torch.full((plan.nrows,), float("nan"), dtype=torch.float64, device=dev)
+    plan.assemble_system(v1, b1, bc=F.BC_POISSON_INLOOP)
+    assert plan.fast_path() == 1
+    assert rel(v1.cpu().numpy(), K) <= TOL and rel(b1.cpu().numpy(), bb) <= TOL
     plan.close()
 
 
