@@ -543,16 +543,13 @@ __global__ __launch_bounds__(512, 2) void k_assemble_p3_hex4(const Slab s, const
         for (int q = 0; q < 9; q++) {
           row[q] = lower[q];
           row[9 + q] = mid[q];
-          row[18 + q] = 0.0;
         }
         ke_gather_p3<0, 0>(sh_ke, glx, gly, row + 9);
-        ke_gather_p3<0, 1>(sh_ke, glx, gly, row + 18);
+        ke_gather_p3<0, 1, true>(sh_ke, glx, gly, row + 18);
       }
       if (start) {
-#pragma unroll
-        for (int q = 0; q < 9; q++) lower[q] = mid[q] = 0.0;
-        ke_gather_p3<1, 0>(sh_ke, glx, gly, lower);
-        ke_gather_p3<1, 1>(sh_ke, glx, gly, mid);
+        ke_gather_p3<1, 0, true>(sh_ke, glx, gly, lower);
+        ke_gather_p3<1, 1, true>(sh_ke, glx, gly, mid);
       }
       __syncthreads();  // Y: the gather is through (the element waves' next step, or their final barrier)
       if (!finish) continue;

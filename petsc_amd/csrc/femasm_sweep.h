@@ -516,8 +516,11 @@ __device__ inline void ke_entries_p3(const double2 *__restrict__ rec /* sh_rec +
 }
 // the entries of the four elements of one element layer that belong to the node's row: AS = 1: the node is on the
 // top face of these elements; OBS: the neighbours on their bottom (0) or top (1) face
-template <int AS, int OBS>
+// FRESH: acc holds nothing yet -- the first contribution of an entry is assigned (the same sums as from zero: 0 + x = x
+// for every x but -0, which a stiffness entry's sign does not distinguish), nine additions fewer per third
+template <int AS, int OBS, bool FRESH = false>
 __device__ inline void ke_gather_p3(const double *__restrict__ ke, int lx, int ly, double *acc) {
+  unsigned seen = FRESH ? 0u : 0x1FFu;  // (folds away: the loops are unrolled)
 #pragma unroll
   for (int oy = -1; oy <= 0; oy++)
 #pragma unroll
@@ -529,7 +532,9 @@ __device__ inline void ke_gather_p3(const double *__restrict__ ke, int lx, int l
 #pragma unroll
         for (int bx = 0; bx <= 1; bx++) {
           const int t = (oy + by + 1) * 3 + (ox + bx + 1);
-          acc[t] = acc[t] + kp[KE_PAIRS.idx[ia][hex_idx(bx, by, OBS)]];
+          const double v = kp[KE_PAIRS.idx[ia][hex_idx(bx, by, OBS)]];
+          acc[t] = ((seen >> t) & 1u) ? acc[t] + v : v;
+          seen |= 1u << t;
         }
     }
 }
