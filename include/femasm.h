@@ -332,7 +332,9 @@ int femasm_plan_sync(femasm_plan *plan);
  * and femasm_interface_apply queue their kernels and return without waiting for the device, so that a driver can post
  * the exchange, start the next slab or set up its solver meanwhile.  The results are final in stream order whatever the
  * mesh: where a verified fast kernel is used, the general kernels are queued behind it and run on the device only if
- * its premise failed.  Geometry errors of such a call are returned by femasm_plan_sync or by the next call on the plan. */
+ * its premise failed.  Geometry errors of such a call are returned by femasm_plan_sync or by the next call on the plan
+ * (when the premise failed, both the fast and the general kernels saw the mesh: the number of bad Gauss points in that
+ * message counts a point once per kernel that met it -- an upper bound, not the synchronous mode's exact count). */
 int femasm_plan_set_async(femasm_plan *plan, int on);
 
 const char *femasm_last_error(void);
